@@ -1,0 +1,219 @@
+/*
+ * libpbe_hip.so — C-ABI of the MI355X (gfx950) native kernels behind Paint-by-Example's
+ * PLMS denoising hot path.
+ *
+ * The reference (zhanwenchen/pbe) is 100 % Python on PyTorch and has NO native layer or FFI
+ * (SURVEY.md "Quick facts"); every entry point below therefore replaces an ATen dispatch made
+ * from a reference Python function, cited per entry as file:line under /root/reference.
+ * The host side (this repo's `ldm/` package, same import paths / class names / state_dict keys
+ * as the reference) binds these symbols with ctypes (pbe_amd/lib.py); INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PBE_E* code; pbe_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - the CALLER allocates every buffer (device memory); the library never allocates, frees or
+ *     retains a pointer.  Kernels are enqueued on `stream` (a hipStream_t) and never synchronise,
+ *     so every call is capturable in a hipGraph.
+ *   - activations are fp16, NHWC ("tokens x channels") unless an entry says otherwise; GEMM and
+ *     attention accumulate in fp32 on the matrix cores; norms / softmax reduce in fp32.
+ *   - descriptors are plain C structs of pointers and sizes (no torch types).
+ */
+#ifndef PBE_HIP_H
+#define PBE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBE_ABI_VERSION 1
+
+#define PBE_OK 0
+#define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
+#define PBE_ELAUNCH (-2) /* hipLaunch failed                              */
+#define PBE_ENOTSUP (-3) /* shape outside what the kernels are built for  */
+
+/* epilogue activations */
+#define PBE_ACT_NONE 0
+#define PBE_ACT_SILU 1
+#define PBE_ACT_GELU_ERF 2
+#define PBE_ACT_QUICK_GELU 3
+
+typedef void* pbe_stream_t; /* hipStream_t */
+
+int pbe_abi_version(void);
+const char* pbe_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * pbe_gemm_f16 — C[m,n] = act(alpha * sum_k A[m,k] * W[n,k] + bias + rowvec[m / group_rows, n]) + R[m,n]
+ * Replaces torch.nn.Linear / 1x1 Conv2d / einsum dispatches:
+ *   ldm/modules/attention.py:198-205,41,61,270-285 (to_q/k/v, to_out, GEGLU proj, FF out, proj_in/out),
+ *   ldm/modules/diffusionmodules/openaimodel.py:218-224,234-241,623-628 (emb_layers, skip 1x1, time_embed),
+ *   ldm/modules/diffusionmodules/model.py:152-204 (VAE q/k/v/proj_out and both bmm's),
+ *   ldm/modules/encoders/xf.py:30-57, transformers CLIP q/k/v/out_proj/fc1/fc2, latent_diffusion.py:112.
+ * A may be split along K into two sources (A | A2 at K1) so torch.cat((h, skip), 1)
+ * (openaimodel.py:883) is never materialised.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pbe_gemm_desc {
+    const void* A;      /* fp16 [M, K1] row-major, leading dim lda                    */
+    const void* A2;     /* fp16 [M, K-K1] or NULL                                     */
+    const void* W;      /* fp16 [N, K] row-major (torch Linear layout), leading dim ldw */
+    void* C;            /* fp16 [M, N], leading dim ldc                               */
+    const float* bias;  /* fp32 [N] (or [M] when bias_per_row) or NULL                */
+    const void* rowvec; /* fp16 [ceil(M/group_rows), ldv] broadcast over row groups, or NULL */
+    const void* resid;  /* fp16 [M, N] leading dim ldr, added AFTER act, or NULL      */
+    int32_t M, N, K, K1;
+    int64_t lda, lda2, ldw, ldc, ldr;
+    int32_t ldv, group_rows;
+    int64_t strideA, strideW, strideC, strideR; /* batch strides (elements)           */
+    int32_t batch;
+    float alpha;
+    int32_t act;
+    int32_t bias_per_row;
+} pbe_gemm_desc;
+int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pbe_conv3x3_f16 — NHWC 3x3 convolution as an implicit GEMM on the matrix cores.
+ *   Y[b,oy,ox,co] = act(sum_{dy,dx,ci} X[b, iy, ix, ci] * Wp[co, (dy*3+dx)*Cin + ci] + bias[co]
+ *                       + rowvec[b, co]) + R[b,oy,ox,co]
+ *   iy = oy*stride + dy - pad (zero outside), optional nearest-2x upsample of X fused in the gather,
+ *   X optionally the channel concat of two tensors (X | X2).
+ * Replaces Conv2d(k=3) dispatches in openaimodel.py:216,229-231 (ResBlock), :109-119 (Upsample:
+ * F.interpolate + conv), :150-160 (Downsample s2 p1), :658-662,824-828 (conv in/out);
+ * model.py:44-81,92-121 (VAE convs; Downsample pad (0,1,0,1) + s2 p0 == pad=0 here).
+ * Requires (C1+C2) % 64 == 0 and C1 % 64 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
+ * Wp is the OIHW weight re-packed by the host to [Cout, 9*Cin] (tap-major, channel-minor).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pbe_conv3x3_desc {
+    const void* X;
+    const void* X2;
+    const void* Wp;
+    void* Y;
+    const float* bias;
+    const void* rowvec; /* fp16 [B, ldv]: per-(sample, channel) add (ResBlock emb, openaimodel.py:273) */
+    const void* resid;  /* fp16 [B,Ho,Wo,Cout] */
+    int32_t B, H, W, C1, C2, Cout;
+    int32_t stride, pad, upsample;
+    int32_t ldv;
+    int32_t act;
+} pbe_conv3x3_desc;
+int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
+
+/* im2col for the three small-Cin convs (9->320 U-Net in, 3->128 VAE in, 4->512 VAE decoder in):
+ * X fp16 NHWC [B,H,W,Cp] -> out fp16 [B*Ho*Wo, 9*Cp]. */
+int pbe_im2col3x3_f16(const void* X, void* out, int32_t B, int32_t H, int32_t W, int32_t Cp,
+                      int32_t stride, int32_t pad, pbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pbe_groupnorm_f16 — GroupNorm(groups) [+ SiLU] over NHWC fp16, fp32 statistics.
+ * Replaces GroupNorm32 (util.py:214-216, eps 1e-5) + SiLU in openaimodel.py:213-215,225-227,824-826;
+ * Normalize (attention.py:77-78 / model.py:40-41, eps 1e-6) + swish (model.py:35-37).
+ * Input may be the channel concat X | X2 (C2 = 0 for a single source).  Output [B, HW, C1+C2].
+ * workspace: pbe_groupnorm_workspace_bytes(B, HW) bytes of device scratch.
+ * ------------------------------------------------------------------------------------------ */
+size_t pbe_groupnorm_workspace_bytes(int32_t B, int32_t HW);
+int pbe_groupnorm_f16(const void* X, const void* X2, const float* gamma, const float* beta, void* Y,
+                      int32_t B, int32_t HW, int32_t C1, int32_t C2, int32_t groups, float eps,
+                      int32_t silu, void* workspace, size_t workspace_bytes, pbe_stream_t stream);
+
+/* pbe_layernorm_f16 — LayerNorm over the last dim C (C % 8 == 0, C <= 2048) of fp16 rows.
+ * Replaces attention.py:240-242 (norm1/3), xf.py:22-28, HF CLIP layer norms. */
+int pbe_layernorm_f16(const void* X, const float* gamma, const float* beta, void* Y, int64_t rows,
+                      int32_t C, int64_t ldx, int64_t ldy, float eps, pbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pbe_attention_f16 — fused softmax(Q K^T * scale) V (flash-style, no [N,N] tensor in HBM).
+ * Replaces attention.py:214-229 (einsum, softmax, einsum) and HF CLIP eager attention.
+ *   Q: fp16, element (b, n, h, d) at Q[b*q_bs + n*q_rs + h*D + d]   (same for K with k_*),
+ *   VT: V transposed, element (b, h, d, n) at VT[b*vt_bs + (h*D+d)*vt_rs + n]  (vt_rs % 8 == 0,
+ *       the row must be readable up to the next multiple of 8 past Nk),
+ *   O: fp16, element (b, n, h, d) at O[b*o_bs + n*o_rs + h*D + d].
+ * D % 8 == 0, D <= 160.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pbe_attn_desc {
+    const void* Q;
+    const void* K;
+    const void* VT;
+    void* O;
+    int32_t B, H, Nq, Nk, D;
+    int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
+    float scale;
+} pbe_attn_desc;
+int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream);
+
+/* pbe_softmax_rows_f16 — Y[r,:] = softmax(scale * X[r,:]) over rows of `cols` fp16 (VAE mid attention,
+ * model.py:193-195: one head, d = 512, N = 4096, scores kept in HBM once per image). */
+int pbe_softmax_rows_f16(const void* X, void* Y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy,
+                         float scale, pbe_stream_t stream);
+
+/* pbe_geglu_f16 — Y[m, f] = H[m, f] * gelu_erf(H[m, F + f])  (attention.py:43-45). */
+int pbe_geglu_f16(const void* H, void* Y, int64_t M, int32_t F, pbe_stream_t stream);
+
+/* pbe_timestep_embedding_f16 — util.py:151-171: out[b, :] = cat(cos(t f_k), sin(t f_k)), fp16 [B, dim]. */
+int pbe_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t dim, float max_period,
+                               pbe_stream_t stream);
+
+/* Layout conversion at the API boundary (the reference API is NCHW fp32/fp16):
+ * src fp32 NCHW [B,C,HW] -> dst fp16 NHWC [B,HW,Cp] (channels C..Cp-1 zero) and back. */
+int pbe_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t B, int32_t C, int32_t HW, int32_t Cp,
+                             pbe_stream_t stream);
+int pbe_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t ld,
+                             pbe_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PLMS sampler element-wise steps (plms.py:177-248), state kept fp32 NCHW [B,4,HW].
+ * pbe_plms_pack_input: x9 = cat(x, z_inpaint, mask) (plms.py:225) duplicated `dup` times along the
+ *   batch for classifier-free guidance (plms.py:185), as fp16 NHWC [dup*B, HW, 16] (9 real channels).
+ * pbe_plms_update: eps_out fp16 NHWC [dup*B, HW, ld] from the U-Net ->
+ *   e_t = e_u + scale (e_c - e_u)                       (plms.py:188-189; dup == 1: e_t = eps_out)
+ *   e'  = c0 e_t + c1 h1 + c2 h2 + c3 h3                (plms.py:230-244; Adams-Bashforth weights)
+ *   pred_x0 = (x - sqrt(1-a_t) e') / sqrt(a_t);  x_prev = sqrt(a_prev) pred_x0 + sqrt(1-a_prev) e'
+ *   coef = {c0,c1,c2,c3, sqrt_one_minus_at, 1/sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)} (host floats).
+ * ------------------------------------------------------------------------------------------ */
+int pbe_plms_pack_input(const float* x, const float* z_inpaint, const float* mask, void* x9,
+                        int32_t B, int32_t HW, int32_t dup, pbe_stream_t stream);
+int pbe_plms_update(const void* eps_out, int32_t ld, int32_t dup, float cfg_scale, const float* x,
+                    const float* h1, const float* h2, const float* h3, const float* coef8,
+                    float* e_t, float* x_prev, float* pred_x0, int32_t B, int32_t HW,
+                    pbe_stream_t stream);
+
+/* pbe_posterior_sample — distributions.py:25-37 + latent_diffusion.py:262:
+ * moments fp16 NHWC [B,HW,ld] (mean 0..3 | logvar 4..7), eps fp32 NCHW [B,4,HW] ->
+ * z fp32 NCHW = scale * (mean + exp(0.5 clamp(logvar,-30,20)) * eps). */
+int pbe_posterior_sample(const void* moments, int32_t ld, const float* eps, float* z, int32_t B,
+                         int32_t HW, float scale, pbe_stream_t stream);
+
+/* pbe_scale_latent_f16 — decode_first_stage prologue (latent_diffusion.py:454,506): fp32 NCHW
+ * [B,C>=4,HW] -> fp16 NHWC [B,HW,8] of (1/scale_factor) * z[:, :4]. */
+int pbe_scale_latent_f16(const float* z, void* out, int32_t B, int32_t C, int32_t HW, float inv_scale,
+                         pbe_stream_t stream);
+
+/* pbe_clip_patchify_f16 — HF CLIPVisionEmbeddings patch conv (14x14 s14, no bias) as im2col:
+ * pixels fp32 NCHW [B,3,S,S] -> fp16 [B*(S/P)^2, Kp], k = c*P*P + ky*P + kx, zero padded to Kp. */
+int pbe_clip_patchify_f16(const float* pixels, void* out, int32_t B, int32_t S, int32_t P, int32_t Kp,
+                          pbe_stream_t stream);
+
+/* pbe_add_rows_f16 — Y[b, r, :] = X[r, :] + V[:]  for r in [0, rows): class-token row of the CLIP
+ * embedding (class_embedding + position_embedding[0]) written to tokens[b, 0, :]. */
+int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t B, int32_t C, int64_t y_bs,
+                      pbe_stream_t stream);
+
+/* pbe_image_post_f32 — scripts/inference.py:347: clamp((x+1)/2, 0, 1) of fp16 NHWC [B,HW,ld] -> fp32 NCHW [B,3,HW]. */
+int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32_t ld, pbe_stream_t stream);
+
+/* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ---- */
+int pbe_prof_enable(int32_t on);
+int pbe_prof_reset(void);
+/* out[3*k + {0,1,2}] = {launches, total ms, total work (flop or bytes)} for class k; returns #classes.
+ * Synchronises the recorded events (call outside any timed region). */
+int pbe_prof_collect(double* out, int32_t max_classes);
+const char* pbe_prof_class_name(int32_t klass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBE_HIP_H */

@@ -1,0 +1,225 @@
+"""Transformer pieces of the U-Net, same class names / constructor arguments / parameter names as
+ldm/modules/attention.py in zhanwenchen/pbe (GEGLU :38-45, FeedForward :48-65, CrossAttention
+:189-230, BasicTransformerBlock :233-252, SpatialTransformer :255-298), executed by HIP kernels:
+
+  * activations stay ``[B, N, C]`` fp16 (tokens x channels == NHWC, so the reference's two
+    rearranges per block are free),
+  * to_q | to_k run as ONE GEMM, to_v as a second GEMM with swapped operands that emits V^T
+    (what the fused attention kernel consumes), softmax(QK^T)V never touches HBM,
+  * the Paint-by-Example context is ONE token per sample, so attn2's softmax over a single key
+    is exactly 1 and ``attn2(x, ctx) = to_out(to_v(ctx))`` for every query (attention.py:207-230;
+    SURVEY.md K6): it is computed once per context as a [B, C] vector and added inside the
+    epilogue of attn1's output projection.  norm2 / attn2.to_q / attn2.to_k keep their
+    parameters (checkpoint compatibility) but are dead arithmetic on this path,
+  * bias, residual and the row-broadcast adds are GEMM epilogues.
+"""
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from pbe_amd import ops
+from pbe_amd.hipmodule import HipModule, f32, require_gpu
+from pbe_amd.lib import PbeError
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if val is not None else (d() if callable(d) else d)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def Normalize(in_channels):
+    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _tokens(x):
+    """[B, N, C] any float dtype -> contiguous fp16 on the GPU."""
+    require_gpu(x, "attention")
+    return x.to(torch.float16).contiguous()
+
+
+class GEGLU(HipModule):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def _pack(self):
+        return SimpleNamespace(w=ops.pack_linear(self.proj.weight), b=f32(self.proj.bias))
+
+    def forward(self, x):
+        p = self.pk()
+        x = _tokens(x)
+        h = ops.gemm(x.view(-1, x.shape[-1]), p.w, p.b)
+        return ops.geglu(h).view(*x.shape[:-1], -1)
+
+
+class FeedForward(HipModule):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        inner = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        if not glu:
+            raise PbeError("FeedForward(glu=False) is not on the Paint-by-Example path (BasicTransformerBlock uses gated_ff=True)")
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out))
+
+    def _pack(self):
+        return SimpleNamespace(w2=ops.pack_linear(self.net[2].weight), b2=f32(self.net[2].bias))
+
+    def run(self, x2d, resid=None):
+        """x2d [M, C] fp16 -> Linear(GEGLU(x)) (+ resid)."""
+        g = self.net[0].pk()
+        p = self.pk()
+        h = ops.geglu(ops.gemm(x2d, g.w, g.b))
+        return ops.gemm(h, p.w2, p.b2, resid=resid)
+
+    def forward(self, x):
+        x = _tokens(x)
+        return self.run(x.view(-1, x.shape[-1])).view(x.shape[0], x.shape[1], -1)
+
+
+class CrossAttention(HipModule):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = default(context_dim, query_dim)
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+
+    def _pack(self):
+        ns = SimpleNamespace(wv=ops.pack_linear(self.to_v.weight), wo=ops.pack_linear(self.to_out[0].weight), bo=f32(self.to_out[0].bias))
+        if self.to_q.weight.shape[1] == self.to_k.weight.shape[1]:
+            ns.wqk = ops.pack_linear(torch.cat([self.to_q.weight, self.to_k.weight], 0))
+        ns.wq, ns.wk = ops.pack_linear(self.to_q.weight), ops.pack_linear(self.to_k.weight)
+        return ns
+
+    # ---- fast paths used by BasicTransformerBlock -------------------------------------------
+    def self_attention(self, xn, B, N):
+        """xn [B*N, C] (already normed) -> per-head softmax(QK^T)V as [B*N, inner] (before to_out)."""
+        p = self.pk()
+        inner = self.heads * self.dim_head
+        qk = ops.gemm(xn, p.wqk)                                              # [M, 2*inner]
+        npad = (N + 7) // 8 * 8
+        vt = torch.empty((B, inner, npad), dtype=torch.float16, device=xn.device)
+        ops.gemm(p.wv.unsqueeze(0).expand(B, -1, -1), xn.view(B, N, -1), out=vt[:, :, :N] if npad != N else vt)
+        o = ops.attention(qk, qk[:, inner:], vt, B, self.heads, N, N, self.dim_head, self.scale,
+                          q_strides=(N * 2 * inner, 2 * inner), k_strides=(N * 2 * inner, 2 * inner), vt_strides=(inner * npad, npad))
+        return o.view(B * N, inner)
+
+    def single_token_context(self, context):
+        """context [B, 1, Dc] -> to_out(to_v(context)) as [B, C] fp16 (softmax over one key == 1)."""
+        p = self.pk()
+        c = _tokens(context)
+        if c.shape[1] != 1:
+            raise PbeError(f"CrossAttention: Paint-by-Example conditions on ONE exemplar token, got {c.shape[1]}")
+        v = ops.gemm(c.view(c.shape[0], -1), p.wv)
+        return ops.gemm(v, p.wo, p.bo)
+
+    # ---- reference-shaped entry point ------------------------------------------------------------
+    def forward(self, x, context=None, mask=None):
+        if exists(mask):
+            raise PbeError("CrossAttention: masks are not used on the Paint-by-Example path")
+        x = _tokens(x)
+        B, N, _ = x.shape
+        p = self.pk()
+        if context is None:
+            o = self.self_attention(x.view(B * N, -1), B, N)
+            return ops.gemm(o, p.wo, p.bo).view(B, N, -1)
+        c = _tokens(context)
+        if c.shape[1] == 1:
+            return self.single_token_context(c)[:, None, :].expand(B, N, -1).contiguous()
+        # general context length (not on the hot path): separate q / k / v projections
+        inner, Nk = self.heads * self.dim_head, c.shape[1]
+        q = ops.gemm(x.view(B * N, -1), p.wq)
+        k = ops.gemm(c.view(B * Nk, -1), p.wk)
+        npad = (Nk + 7) // 8 * 8
+        vt = torch.zeros((B, inner, npad), dtype=torch.float16, device=x.device)
+        ops.gemm(p.wv.unsqueeze(0).expand(B, -1, -1), c, out=vt[:, :, :Nk] if npad != Nk else vt)
+        o = ops.attention(q, k, vt, B, self.heads, N, Nk, self.dim_head, self.scale, q_strides=(N * inner, inner),
+                          k_strides=(Nk * inner, inner), vt_strides=(inner * npad, npad))
+        return ops.gemm(o.view(B * N, inner), p.wo, p.bo).view(B, N, -1)
+
+
+class BasicTransformerBlock(HipModule):
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    def _pack(self):
+        return SimpleNamespace(g1=f32(self.norm1.weight), b1=f32(self.norm1.bias), g3=f32(self.norm3.weight), b3=f32(self.norm3.bias),
+                               eps1=self.norm1.eps, eps3=self.norm3.eps)
+
+    def run(self, x2d, B, N, ctx_vec):
+        """x2d [B*N, C] fp16 residual stream; ctx_vec [B, C] = attn2's constant (single_token_context)."""
+        p = self.pk()
+        a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
+        a1 = self.attn1.pk()
+        x1 = ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec, group_rows=N, resid=x2d)          # attn1 + x, + attn2 constant
+        return self.ff.run(ops.layernorm(x1, p.g3, p.b3, p.eps3), resid=x1)
+
+    def forward(self, x, context=None):
+        x = _tokens(x)
+        B, N, Cc = x.shape
+        if context is None or context.shape[1] != 1:
+            raise PbeError("BasicTransformerBlock: the HIP path expects a one-token context [B, 1, D]")
+        return self.run(x.view(B * N, Cc), B, N, self.attn2.single_token_context(context)).view(B, N, Cc)
+
+
+class SpatialTransformer(HipModule):
+    """GroupNorm(eps 1e-6) -> 1x1 proj_in -> transformer block(s) -> 1x1 proj_out -> + input."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None):
+        super().__init__()
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim) for _ in range(depth)])
+        self.proj_out = zero_module(nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0))
+
+    def _pack(self):
+        return SimpleNamespace(g=f32(self.norm.weight), b=f32(self.norm.bias), eps=self.norm.eps,
+                               wi=ops.pack_linear(self.proj_in.weight), bi=f32(self.proj_in.bias),
+                               wo=ops.pack_linear(self.proj_out.weight), bo=f32(self.proj_out.bias))
+
+    def context_vectors(self, context):
+        return [blk.attn2.single_token_context(context) for blk in self.transformer_blocks]
+
+    def run(self, x, ctx_vecs):
+        """x [B, H, W, C] fp16 NHWC -> same shape."""
+        p = self.pk()
+        B, H, W, Cc = x.shape
+        N = H * W
+        h = ops.gemm(ops.groupnorm(x, p.g, p.b, p.eps, False).view(B * N, Cc), p.wi, p.bi)
+        for blk, cv in zip(self.transformer_blocks, ctx_vecs):
+            h = blk.run(h, B, N, cv)
+        return ops.gemm(h, p.wo, p.bo, resid=x.view(B * N, Cc)).view(B, H, W, Cc)
+
+    def forward(self, x, context=None):
+        """Reference layout: x [B, C, H, W] -> [B, C, H, W]."""
+        require_gpu(x, "SpatialTransformer")
+        if context is None:
+            raise PbeError("SpatialTransformer: context is required on the Paint-by-Example path")
+        y = self.run(ops.nchw_to_nhwc(x.float()), self.context_vectors(context))
+        return ops.nhwc_to_nchw(y).to(x.dtype)

@@ -1,0 +1,265 @@
+// Fused multi-head attention forward, softmax(Q K^T * scale) V, for gfx950 (wave64, MFMA 32x32x16 f16).
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries for the
+// whole K/V sweep.  K/V^T tiles of 64 keys are staged global -> registers -> LDS (next tile's
+// loads in flight under the current tile's MFMAs, two LDS buffers, one barrier per tile).
+//
+// The score tile is computed TRANSPOSED, S^T = K Q^T, so the query index sits on the lane
+// (column of the 32x32 accumulator) and the 32 keys of a sub-tile sit in the lane's registers:
+// the row max / row sum are register-local plus ONE cross-half exchange, and the exponentiated
+// accumulator registers feed the second product O^T = V^T P^T directly as its B operand (no LDS
+// round trip, no shuffles) — the k order inside each 16-key step is permuted
+// (key = 16s + 8(j>>2) + 4h + (j&3)), so the V^T fragment is read with the same permutation.
+// V therefore arrives already transposed ([head*D + d][key], produced for free by the
+// projection GEMM with swapped operands), its tile rows padded to 136 B (conflict-free
+// ds_read_b64); K tile rows padded to an odd number of 16-B units (conflict-free ds_read_b128).
+#include "common.h"
+#include "../../include/pbe_hip.h"
+
+struct AttnP {
+    const h16* Q; const h16* K; const h16* VT; h16* O;
+    int B, H, Nq, Nk, D;
+    long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
+    float scale_log2e;
+};
+
+template <int DP>
+__global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
+    constexpr int DV = (DP + 31) / 32 * 32;
+    constexpr int NDS = DP / 16;          // k-steps of the QK^T product
+    constexpr int NDT = DV / 32;          // 32-wide d tiles of the output
+    constexpr int DC = DP / 8;            // 16-B chunks per K row
+    constexpr int KSTR = (DC | 1) * 16;   // K tile row stride, bytes (odd number of 16-B units)
+    constexpr int VSTR = 136;             // V^T tile row stride, bytes
+    constexpr int K_BYTES = 64 * KSTR;
+    constexpr int V_BYTES = DV * VSTR;
+    constexpr int BUF = (K_BYTES + V_BYTES + 15) / 16 * 16;
+    constexpr int KCH = 64 * DC, NKL = (KCH + 255) / 256;
+    constexpr int VCH = DV * 8, NVL = (VCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h5 = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int D = p.D;
+    const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const h16* Qb = p.Q + (long)b * p.q_bs + (long)h * D;
+    const h16* Kb = p.K + (long)b * p.k_bs + (long)h * D;
+    const h16* Vb = p.VT + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
+
+    // Q fragments (B operand of S^T = K Q^T): lane = query column, 8 consecutive d per k-step half
+    h16x8 qf[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        const int d0 = ds * 16 + 8 * h5;
+        const bool ok = q < p.Nq && d0 < D;
+        const h16* src = ok ? Qb + (long)q * p.q_rs + d0 : p.Q;
+        h16x8 v = *reinterpret_cast<const h16x8*>(src);
+        qf[ds] = ok ? v : zero8;
+    }
+
+    h16x8 rk[NKL], rv[NVL];
+    auto load_tile = [&](int t) {
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / DC, ch = idx - row * DC;
+            const bool ok = idx < KCH && (kv0 + row) < p.Nk && ch * 8 < D;
+            const h16* src = ok ? Kb + (long)(kv0 + row) * p.k_rs + ch * 8 : p.K;
+            h16x8 v = *reinterpret_cast<const h16x8*>(src);
+            rk[i] = ok ? v : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, ch = idx & 7;
+            const int key0 = kv0 + ch * 8;
+            const bool ok = idx < VCH && row < D && key0 < p.Nk;
+            const h16* src = ok ? Vb + (long)row * p.vt_rs + key0 : p.VT;
+            h16x8 v = *reinterpret_cast<const h16x8*>(src);
+            v = ok ? v : zero8;
+            if (ok && key0 + 8 > p.Nk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (key0 + e >= p.Nk) v[e] = (h16)0.f;
+            }
+            rv[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sk = smem + buf * BUF;
+        unsigned char* sv = sk + K_BYTES;
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / DC, ch = idx - row * DC;
+            if (idx < KCH) *reinterpret_cast<h16x8*>(sk + row * KSTR + ch * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 3, ch = idx & 7;
+            if (idx < VCH) {
+                h16x4 lo = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
+                h16x4 hi = {rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
+                *reinterpret_cast<h16x4*>(sv + row * VSTR + ch * 16) = lo;
+                *reinterpret_cast<h16x4*>(sv + row * VSTR + ch * 16 + 8) = hi;
+            }
+        }
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.Nk + 63) >> 6;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        const unsigned char* sk = smem + cur * BUF;
+        const unsigned char* sv = sk + K_BYTES;
+
+        // ---- S^T = K Q^T : two 32-key sub-tiles ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
+            const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ds], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ds], s1, 0, 0, 0);
+        }
+        // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32) ----
+        const int kv0 = t * 64;
+        const bool tail = kv0 + 64 > p.Nk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s0[r] * p.scale_log2e, c = s1[r] * p.scale_log2e;
+            if (tail) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+                if (key >= p.Nk) a = -INFINITY;
+                if (key + 32 >= p.Nk) c = -INFINITY;
+            }
+            s0[r] = a; s1[r] = c;
+            mx = fmaxf(mx, fmaxf(a, c));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- P^T fragments straight from the accumulator registers (permuted k order) ----
+        h16x8 pf[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pf[0][j] = (h16)s0[j];
+            pf[1][j] = (h16)s0[8 + j];
+            pf[2][j] = (h16)s1[j];
+            pf[3][j] = (h16)s1[8 + j];
+        }
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + 8 * h5;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {   // ks = sub*2 + s : keys sub*32 + 16 s + {4h..4h+3, 8+4h..}
+                const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow + ks * 32);
+                const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + ks * 32 + 16);
+                const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[q, h*D + d] ----
+    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l;
+    if (q < p.Nq) {
+        h16* Ob = p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h5;
+                if (d0 < D) {
+                    h16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (h16)(o[dt][4 * g + r] * inv);
+                    *reinterpret_cast<h16x4*>(Ob + d0) = v;
+                }
+            }
+    }
+}
+
+template <int DP>
+static void launch_attn(const AttnP& p, hipStream_t s) {
+    constexpr int DV = (DP + 31) / 32 * 32;
+    constexpr int KSTR = ((DP / 8) | 1) * 16;
+    constexpr int BUF = (64 * KSTR + DV * 136 + 15) / 16 * 16;
+    constexpr size_t lds = 2 * BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
+    hipLaunchKernelGGL((attn_kernel<DP>), grid, dim3(256), lds, s, p);
+}
+
+extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
+    PBE_REQUIRE(d && d->Q && d->K && d->VT && d->O, "pbe_attention_f16: null operand");
+    PBE_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "pbe_attention_f16: bad dims");
+    PBE_REQUIRE(d->D % 8 == 0 && d->D >= 8 && d->D <= 160, "pbe_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d->D);
+    PBE_REQUIRE(d->q_rs % 8 == 0 && d->k_rs % 8 == 0 && d->vt_rs % 8 == 0 && d->o_rs % 8 == 0 &&
+                d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->vt_bs % 8 == 0 && d->o_bs % 8 == 0,
+                "pbe_attention_f16: strides must be multiples of 8 elements");
+    PBE_REQUIRE(d->vt_rs >= (d->Nk + 7) / 8 * 8, "pbe_attention_f16: vt_rs must cover Nk rounded up to 8");
+    PBE_REQUIRE(((uintptr_t)d->Q & 15) == 0 && ((uintptr_t)d->K & 15) == 0 && ((uintptr_t)d->VT & 15) == 0 && ((uintptr_t)d->O & 15) == 0,
+                "pbe_attention_f16: 16-byte alignment");
+    PBE_REQUIRE((long)d->B * d->H <= 65535, "pbe_attention_f16: B*H too large");
+    AttnP p;
+    p.Q = (const h16*)d->Q; p.K = (const h16*)d->K; p.VT = (const h16*)d->VT; p.O = (h16*)d->O;
+    p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk; p.D = d->D;
+    p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.k_bs = d->k_bs; p.k_rs = d->k_rs;
+    p.vt_bs = d->vt_bs; p.vt_rs = d->vt_rs; p.o_bs = d->o_bs; p.o_rs = d->o_rs;
+    p.scale_log2e = d->scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    pbe_prof_begin(PBE_K_ATTN, s);
+    const int D = d->D;
+    if (D <= 16) launch_attn<16>(p, s);
+    else if (D <= 32) launch_attn<32>(p, s);
+    else if (D <= 48) launch_attn<48>(p, s);
+    else if (D <= 64) launch_attn<64>(p, s);
+    else if (D <= 80) launch_attn<80>(p, s);
+    else if (D <= 128) launch_attn<128>(p, s);
+    else launch_attn<160>(p, s);
+    pbe_prof_end(PBE_K_ATTN, s, 4.0 * d->B * d->H * (double)d->Nq * d->Nk * d->D);
+    PBE_LAUNCH_CHECK("pbe_attention_f16");
+    return PBE_OK;
+}

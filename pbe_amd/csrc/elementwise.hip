@@ -1,0 +1,282 @@
+// Small HBM / launch-latency bound kernels around the matrix-core ops: layout conversion at the
+// NCHW API boundary, im2col for the three tiny-Cin convs, GEGLU, timestep embedding, the fused
+// PLMS sampler update, VAE posterior sampling, CLIP patchify.
+#include "common.h"
+#include "../../include/pbe_hip.h"
+
+#define EW_GRID(n) dim3((unsigned)(((n) + 255) / 256))
+#define EW_BEGIN(s) pbe_prof_begin(PBE_K_ELEM, s)
+#define EW_END(s, bytes, name) \
+    pbe_prof_end(PBE_K_ELEM, s, bytes); \
+    PBE_LAUNCH_CHECK(name); \
+    return PBE_OK
+
+// ---- NCHW fp32 <-> NHWC fp16 -------------------------------------------------------------------
+__global__ void nchw2nhwc_kernel(const float* src, h16* dst, int C, int HW, int Cp, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*HW pixels
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+    h16* d = dst + i * Cp;
+    for (int c = 0; c < Cp; ++c) d[c] = (h16)(c < C ? src[(b * C + c) * HW + px] : 0.f);
+}
+extern "C" int pbe_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t B, int32_t C, int32_t HW, int32_t Cp, pbe_stream_t stream) {
+    PBE_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && Cp >= C, "pbe_nchw_f32_to_nhwc_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(nchw2nhwc_kernel, EW_GRID(total), dim3(256), 0, s, src, (h16*)dst, C, HW, Cp, total);
+    EW_END(s, (double)total * (4.0 * C + 2.0 * Cp), "pbe_nchw_f32_to_nhwc_f16");
+}
+
+__global__ void nhwc2nchw_kernel(const h16* src, float* dst, int C, int HW, int ld, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+    const h16* s = src + i * ld;
+    for (int c = 0; c < C; ++c) dst[(b * C + c) * HW + px] = (float)s[c];
+}
+extern "C" int pbe_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t ld, pbe_stream_t stream) {
+    PBE_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && ld >= C, "pbe_nhwc_f16_to_nchw_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(nhwc2nchw_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)src, dst, C, HW, ld, total);
+    EW_END(s, (double)total * 6.0 * C, "pbe_nhwc_f16_to_nchw_f32");
+}
+
+// ---- im2col 3x3 for tiny Cin (Cp in {8,16}) ------------------------------------------------------
+__global__ void im2col3x3_kernel(const h16* X, h16* out, int H, int W, int Cp, int Ho, int Wo, int stride, int pad, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over M * 9 (pixel, tap)
+    if (i >= total) return;
+    const long m = i / 9;
+    const int tap = (int)(i - m * 9), dy = tap / 3, dx = tap - dy * 3;
+    const int hw = Ho * Wo;
+    const long b = m / hw;
+    const int rem = (int)(m - b * hw), oy = rem / Wo, ox = rem - oy * Wo;
+    const int iy = oy * stride + dy - pad, ix = ox * stride + dx - pad;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const h16x8* src = reinterpret_cast<const h16x8*>(X + ((b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cp);
+    h16x8* dst = reinterpret_cast<h16x8*>(out + (m * 9 + tap) * Cp);
+    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < Cp / 8; ++v) dst[v] = ok ? src[v] : z;
+}
+extern "C" int pbe_im2col3x3_f16(const void* X, void* out, int32_t B, int32_t H, int32_t W, int32_t Cp, int32_t stride, int32_t pad,
+                                 pbe_stream_t stream) {
+    PBE_REQUIRE(X && out && B > 0 && H > 0 && W > 0, "pbe_im2col3x3_f16: bad arguments");
+    PBE_REQUIRE(Cp % 8 == 0 && Cp > 0, "pbe_im2col3x3_f16: Cp must be a multiple of 8");
+    PBE_REQUIRE((stride == 1 || stride == 2) && (pad == 0 || pad == 1), "pbe_im2col3x3_f16: stride/pad");
+    const int extra = pad ? 2 : 1;
+    const int Ho = (H + extra - 3) / stride + 1, Wo = (W + extra - 3) / stride + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * Ho * Wo * 9;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(im2col3x3_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)X, (h16*)out, H, W, Cp, Ho, Wo, stride, pad, total);
+    EW_END(s, (double)total * Cp * 4.0, "pbe_im2col3x3_f16");
+}
+
+// ---- GEGLU ---------------------------------------------------------------------------------------
+__global__ void geglu_kernel(const h16* Hh, h16* Y, int F8, long F, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over M * F/8
+    if (i >= total) return;
+    const long m = i / F8;
+    const int v = (int)(i - m * F8);
+    const h16x8 a = *reinterpret_cast<const h16x8*>(Hh + m * 2 * F + v * 8);
+    const h16x8 g = *reinterpret_cast<const h16x8*>(Hh + m * 2 * F + F + v * 8);
+    h16x8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (h16)((float)a[e] * gelu_erf_f((float)g[e]));
+    *reinterpret_cast<h16x8*>(Y + m * F + v * 8) = y;
+}
+extern "C" int pbe_geglu_f16(const void* Hh, void* Y, int64_t M, int32_t F, pbe_stream_t stream) {
+    PBE_REQUIRE(Hh && Y && M > 0 && F > 0 && F % 8 == 0, "pbe_geglu_f16: bad arguments (F %% 8 == 0)");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)M * (F / 8);
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(geglu_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)Hh, (h16*)Y, F / 8, (long)F, total);
+    EW_END(s, (double)M * F * 6.0, "pbe_geglu_f16");
+}
+
+// ---- timestep embedding --------------------------------------------------------------------------
+__global__ void temb_kernel(const int64_t* t, h16* out, int dim, float neg_log_period_over_half, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B * dim
+    if (i >= total) return;
+    const int b = (int)(i / dim), j = (int)(i - (long)b * dim), half = dim / 2;
+    float v = 0.f;
+    if (j < 2 * half) {
+        const int k = j < half ? j : j - half;
+        const float freq = expf(neg_log_period_over_half * (float)k);
+        const float arg = (float)t[b] * freq;
+        v = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = (h16)v;
+}
+extern "C" int pbe_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t dim, float max_period, pbe_stream_t stream) {
+    PBE_REQUIRE(t && out && B > 0 && dim >= 2 && max_period > 1.f, "pbe_timestep_embedding_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * dim;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(temb_kernel, EW_GRID(total), dim3(256), 0, s, t, (h16*)out, dim, -logf(max_period) / (float)(dim / 2), total);
+    EW_END(s, (double)total * 2.0, "pbe_timestep_embedding_f16");
+}
+
+// ---- PLMS sampler ------------------------------------------------------------------------------
+__global__ void plms_pack_kernel(const float* x, const float* z, const float* mask, h16* x9, int B, int HW, int dup, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*HW
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+    h16 v[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { v[c] = (h16)x[(b * 4 + c) * HW + px]; v[4 + c] = (h16)z[(b * 4 + c) * HW + px]; }
+    v[8] = (h16)mask[b * HW + px];
+#pragma unroll
+    for (int c = 9; c < 16; ++c) v[c] = (h16)0.f;
+    const h16x8 lo = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    const h16x8 hi = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+    for (int d = 0; d < dup; ++d) {
+        h16x8* dst = reinterpret_cast<h16x8*>(x9 + ((long)d * B * HW + i) * 16);
+        dst[0] = lo; dst[1] = hi;
+    }
+}
+extern "C" int pbe_plms_pack_input(const float* x, const float* z_inpaint, const float* mask, void* x9, int32_t B, int32_t HW, int32_t dup,
+                                   pbe_stream_t stream) {
+    PBE_REQUIRE(x && z_inpaint && mask && x9 && B > 0 && HW > 0 && (dup == 1 || dup == 2), "pbe_plms_pack_input: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(plms_pack_kernel, EW_GRID(total), dim3(256), 0, s, x, z_inpaint, mask, (h16*)x9, B, HW, dup, total);
+    EW_END(s, (double)total * (36.0 + 32.0 * dup), "pbe_plms_pack_input");
+}
+
+struct PlmsCoef { float c[8]; };
+__global__ void plms_update_kernel(const h16* eps, int ld, int dup, float cfg, const float* x, const float* h1, const float* h2,
+                                   const float* h3, PlmsCoef k, float* e_t, float* x_prev, float* pred_x0, int B, int HW, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*4*HW (NCHW order)
+    if (i >= total) return;
+    const long b = i / (4L * HW);
+    const int rem = (int)(i - b * 4L * HW), c = rem / HW, px = rem - c * HW;
+    const long tok = b * HW + px;
+    float e;
+    if (dup == 2) {
+        const float eu = (float)eps[tok * ld + c], ec = (float)eps[((long)B * HW + tok) * ld + c];
+        e = eu + cfg * (ec - eu);
+    } else {
+        e = (float)eps[tok * ld + c];
+    }
+    float ep = k.c[0] * e;
+    if (h1) ep += k.c[1] * h1[i];
+    if (h2) ep += k.c[2] * h2[i];
+    if (h3) ep += k.c[3] * h3[i];
+    const float px0 = (x[i] - k.c[4] * ep) * k.c[5];
+    if (e_t) e_t[i] = e;
+    if (pred_x0) pred_x0[i] = px0;
+    x_prev[i] = k.c[6] * px0 + k.c[7] * ep;
+}
+extern "C" int pbe_plms_update(const void* eps_out, int32_t ld, int32_t dup, float cfg_scale, const float* x, const float* h1, const float* h2,
+                               const float* h3, const float* coef8, float* e_t, float* x_prev, float* pred_x0, int32_t B, int32_t HW,
+                               pbe_stream_t stream) {
+    PBE_REQUIRE(eps_out && x && coef8 && x_prev && B > 0 && HW > 0 && ld >= 4 && (dup == 1 || dup == 2), "pbe_plms_update: bad arguments");
+    PlmsCoef k;
+    for (int i = 0; i < 8; ++i) k.c[i] = coef8[i];
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 4 * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(plms_update_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)eps_out, ld, dup, cfg_scale, x, h1, h2, h3, k, e_t,
+                       x_prev, pred_x0, B, HW, total);
+    EW_END(s, (double)total * 32.0, "pbe_plms_update");
+}
+
+// ---- VAE posterior sample / latent un-scale / image post ---------------------------------------
+__global__ void posterior_kernel(const h16* mom, int ld, const float* eps, float* z, int HW, float scale, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*4*HW
+    if (i >= total) return;
+    const long b = i / (4L * HW);
+    const int rem = (int)(i - b * 4L * HW), c = rem / HW, px = rem - c * HW;
+    const h16* m = mom + (b * HW + px) * ld;
+    const float mean = (float)m[c];
+    const float logvar = fminf(fmaxf((float)m[4 + c], -30.f), 20.f);
+    z[i] = scale * (mean + expf(0.5f * logvar) * eps[i]);
+}
+extern "C" int pbe_posterior_sample(const void* moments, int32_t ld, const float* eps, float* z, int32_t B, int32_t HW, float scale,
+                                    pbe_stream_t stream) {
+    PBE_REQUIRE(moments && eps && z && B > 0 && HW > 0 && ld >= 8, "pbe_posterior_sample: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 4 * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(posterior_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)moments, ld, eps, z, HW, scale, total);
+    EW_END(s, (double)total * 12.0, "pbe_posterior_sample");
+}
+
+__global__ void scale_latent_kernel(const float* z, h16* out, int C, int HW, float inv_scale, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*HW
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+    h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (h16)(z[(b * C + c) * HW + px] * inv_scale);
+    *reinterpret_cast<h16x8*>(out + i * 8) = v;
+}
+extern "C" int pbe_scale_latent_f16(const float* z, void* out, int32_t B, int32_t C, int32_t HW, float inv_scale, pbe_stream_t stream) {
+    PBE_REQUIRE(z && out && B > 0 && C >= 4 && HW > 0, "pbe_scale_latent_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(scale_latent_kernel, EW_GRID(total), dim3(256), 0, s, z, (h16*)out, C, HW, inv_scale, total);
+    EW_END(s, (double)total * 32.0, "pbe_scale_latent_f16");
+}
+
+__global__ void image_post_kernel(const h16* src, float* dst, int HW, int ld, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*HW
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(b * 3 + c) * HW + px] = fminf(fmaxf(((float)src[i * ld + c] + 1.f) * 0.5f, 0.f), 1.f);
+}
+extern "C" int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32_t ld, pbe_stream_t stream) {
+    PBE_REQUIRE(src && dst && B > 0 && HW > 0 && ld >= 3, "pbe_image_post_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(image_post_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)src, dst, HW, ld, total);
+    EW_END(s, (double)total * 18.0, "pbe_image_post_f32");
+}
+
+// ---- CLIP patchify / class-token row ------------------------------------------------------------
+__global__ void clip_patchify_kernel(const float* px, h16* out, int S, int P, int Kp, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*G*G*Kp
+    if (i >= total) return;
+    const int G = S / P;
+    const long tokn = i / Kp;
+    const int k = (int)(i - tokn * Kp);
+    float v = 0.f;
+    if (k < 3 * P * P) {
+        const long b = tokn / (G * G);
+        const int t = (int)(tokn - b * G * G), gy = t / G, gx = t - gy * G;
+        const int c = k / (P * P), r = k - c * P * P, ky = r / P, kx = r - ky * P;
+        v = px[((b * 3 + c) * S + gy * P + ky) * S + gx * P + kx];
+    }
+    out[i] = (h16)v;
+}
+extern "C" int pbe_clip_patchify_f16(const float* pixels, void* out, int32_t B, int32_t S, int32_t P, int32_t Kp, pbe_stream_t stream) {
+    PBE_REQUIRE(pixels && out && B > 0 && S > 0 && P > 0 && S % P == 0 && Kp >= 3 * P * P && Kp % 8 == 0, "pbe_clip_patchify_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * (S / P) * (S / P) * Kp;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(clip_patchify_kernel, EW_GRID(total), dim3(256), 0, s, pixels, (h16*)out, S, P, Kp, total);
+    EW_END(s, (double)total * 6.0, "pbe_clip_patchify_f16");
+}
+
+__global__ void bcast_row_kernel(const h16* a, const h16* b, h16* Y, int C, long y_bs, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*C
+    if (i >= total) return;
+    const long bb = i / C;
+    const int c = (int)(i - bb * C);
+    Y[bb * y_bs + c] = (h16)((float)a[c] + (float)b[c]);
+}
+extern "C" int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t B, int32_t C, int64_t y_bs, pbe_stream_t stream) {
+    PBE_REQUIRE(a && b && Y && B > 0 && C > 0, "pbe_bcast_row_f16: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * C;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(bcast_row_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)a, (const h16*)b, (h16*)Y, C, (long)y_bs, total);
+    EW_END(s, (double)total * 6.0, "pbe_bcast_row_f16");
+}

@@ -1,0 +1,274 @@
+// HBM-bound normalisation kernels: GroupNorm(+SiLU) over NHWC, LayerNorm, row softmax.
+// All loads/stores are 16 bytes per lane (8 fp16), statistics in fp32 (finalised in fp64).
+#include "common.h"
+#include "../../include/pbe_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm.  NHWC rows are contiguous, so thread (ty, tx) with tx = 8-channel vector index and
+// ty = row-in-pass addresses x + (row * C8 + tx) * 16 B: consecutive lanes -> consecutive 16-B
+// segments.  Pass 1 (gn_stats): per-block partial (sum, sumsq) per group -> workspace.
+// Pass 2 (gn_apply): finalise mean / rstd per (b, group) from the partials, then stream
+// y = silu((x - mean) * rstd * gamma + beta).
+// The input may be a channel concat of two tensors (vector index < C1/8 -> X, else X2).
+// ------------------------------------------------------------------------------------------------
+#define GN_MAX_C 4096
+#define GN_MAX_CHUNKS 256
+
+__device__ __forceinline__ const h16* gn_src(const h16* X, const h16* X2, int C1, int C2, long row, int v) {
+    const int c = v * 8;
+    return (c < C1) ? X + row * C1 + c : X2 + row * C2 + (c - C1);
+}
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const h16* X, const h16* X2, float* part, int HW, int C1, int C2,
+                                                        int groups, int rows_per_block, int TX, int TY) {
+    __shared__ float s_sum[GN_MAX_C], s_sq[GN_MAX_C];
+    const int C = C1 + C2, C8 = C >> 3, cg = C / groups;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int r0 = chunk * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
+    if (ty < TY) {
+        for (int v = tx; v < C8; v += TX) {
+            float a[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
+            for (int r = r0 + ty; r < r1; r += TY) {
+                const h16x8 x = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, (long)b * HW + r, v));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; a[e] += f; q[e] += f * f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[v * 8 + e], a[e]); atomicAdd(&s_sq[v * 8 + e], q[e]); }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += s_sum[c]; q += s_sq[c]; }
+        float* dst = part + (((long)b * gridDim.x + chunk) * groups + tid) * 2;
+        dst[0] = a; dst[1] = q;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const h16* X, const h16* X2, const float* part, const float* gamma,
+                                                        const float* beta, h16* Y, int HW, int C1, int C2, int groups,
+                                                        int nchunks, int rows_per_block, int TX, int TY, float eps, int silu) {
+    __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_a[256], s_q[256];
+    const int C = C1 + C2, C8 = C >> 3, cg = C / groups;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int b = blockIdx.y;
+    {   // finalise statistics: thread -> (group g, slice sl of the partial list)
+        const int slices = 256 / groups;                 // groups <= 64
+        const int g = tid % groups, sl = tid / groups;
+        double a = 0.0, q = 0.0;
+        if (sl < slices)
+            for (int c = sl; c < nchunks; c += slices) {
+                const float* src = part + (((long)b * nchunks + c) * groups + g) * 2;
+                a += (double)src[0]; q += (double)src[1];
+            }
+        s_a[tid] = a; s_q[tid] = q;
+        __syncthreads();
+        if (tid < groups) {
+            double ta = 0.0, tq = 0.0;
+            for (int s = 0; s < slices; ++s) { ta += s_a[s * groups + tid]; tq += s_q[s * groups + tid]; }
+            const double n = (double)HW * cg;
+            const double mean = ta / n;
+            double var = tq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[tid] = (float)mean;
+            s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
+    if (ty >= TY) return;
+    for (int v = tx; v < C8; v += TX) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = v * 8 + e, g = c / cg;
+            const float a = s_rstd[g] * gamma[c];
+            sc[e] = a; sh[e] = beta[c] - s_mean[g] * a;
+        }
+        for (int r = r0 + ty; r < r1; r += TY) {
+            const long row = (long)b * HW + r;
+            const h16x8 x = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, row, v));
+            h16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)x[e] * sc[e] + sh[e];
+                if (silu) f = silu_f(f);
+                y[e] = (h16)f;
+            }
+            *reinterpret_cast<h16x8*>(Y + row * C + v * 8) = y;
+        }
+    }
+}
+
+static void gn_geometry(int HW, int C, int* nchunks, int* rpb, int* TX, int* TY) {
+    const int C8 = C / 8;
+    *TX = C8 < 256 ? C8 : 256;
+    *TY = 256 / *TX;
+    int rows = *TY * 8;                       // >= 8 rows per thread-row per block
+    if (rows < 32) rows = 32;
+    int n = (HW + rows - 1) / rows;
+    if (n > GN_MAX_CHUNKS) { n = GN_MAX_CHUNKS; rows = (HW + n - 1) / n; n = (HW + rows - 1) / rows; }
+    *nchunks = n; *rpb = rows;
+}
+
+extern "C" size_t pbe_groupnorm_workspace_bytes(int32_t B, int32_t HW) {
+    (void)HW;
+    return (size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float);
+}
+
+extern "C" int pbe_groupnorm_f16(const void* X, const void* X2, const float* gamma, const float* beta, void* Y, int32_t B,
+                                 int32_t HW, int32_t C1, int32_t C2, int32_t groups, float eps, int32_t silu, void* workspace,
+                                 size_t workspace_bytes, pbe_stream_t stream) {
+    const int C = C1 + C2;
+    PBE_REQUIRE(X && gamma && beta && Y && workspace, "pbe_groupnorm_f16: null operand");
+    PBE_REQUIRE(B > 0 && HW > 0 && C1 > 0 && C2 >= 0, "pbe_groupnorm_f16: bad dims");
+    PBE_REQUIRE((C2 == 0) == (X2 == nullptr), "pbe_groupnorm_f16: X2 / C2 mismatch");
+    PBE_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C <= GN_MAX_C, "pbe_groupnorm_f16: C1=%d C2=%d must be multiples of 8, total <= %d", C1, C2, GN_MAX_C);
+    PBE_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "pbe_groupnorm_f16: groups=%d must divide C=%d (<= 64)", groups, C);
+    PBE_REQUIRE(B <= 65535, "pbe_groupnorm_f16: batch too large");
+    PBE_REQUIRE(workspace_bytes >= pbe_groupnorm_workspace_bytes(B, HW), "pbe_groupnorm_f16: workspace too small");
+    int nchunks, rpb, TX, TY;
+    gn_geometry(HW, C, &nchunks, &rpb, &TX, &TY);
+    hipStream_t s = (hipStream_t)stream;
+    pbe_prof_begin(PBE_K_GNORM, s);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (float*)workspace, HW, C1, C2,
+                       groups, rpb, TX, TY);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (const float*)workspace, gamma,
+                       beta, (h16*)Y, HW, C1, C2, groups, nchunks, rpb, TX, TY, eps, silu);
+    pbe_prof_end(PBE_K_GNORM, s, 6.0 * B * (double)HW * C);   // bytes: read x twice, write y once
+    PBE_LAUNCH_CHECK("pbe_groupnorm_f16");
+    return PBE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row held in registers (<= 4 x 8 halfs per lane), two wave
+// reductions (mean, then centred variance — same two-pass form as torch's CPU kernel).
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_kernel(const h16* X, const float* gamma, const float* beta, h16* Y, long rows, int C,
+                                                         long ldx, long ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    h16x8 x[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            x[i] = *reinterpret_cast<const h16x8*>(X + row * ldx + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)x[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)x[i][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+            h16x8 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (h16)(((float)x[i][e] - mean) * rstd * g0[e] + b0[e]);
+                y[4 + e] = (h16)(((float)x[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+            }
+            *reinterpret_cast<h16x8*>(Y + row * ldy + v * 8) = y;
+        }
+    }
+}
+
+extern "C" int pbe_layernorm_f16(const void* X, const float* gamma, const float* beta, void* Y, int64_t rows, int32_t C, int64_t ldx,
+                                 int64_t ldy, float eps, pbe_stream_t stream) {
+    PBE_REQUIRE(X && gamma && beta && Y, "pbe_layernorm_f16: null operand");
+    PBE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, "pbe_layernorm_f16: C=%d must be a multiple of 8, <= 2048", C);
+    PBE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "pbe_layernorm_f16: bad leading dims");
+    PBE_REQUIRE(((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0, "pbe_layernorm_f16: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    pbe_prof_begin(PBE_K_LNORM, s);
+    const int vpl = (C / 8 + 63) / 64;
+    if (vpl <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, (const h16*)X, gamma, beta, (h16*)Y, (long)rows, C, (long)ldx, (long)ldy, eps);
+    else if (vpl == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, (const h16*)X, gamma, beta, (h16*)Y, (long)rows, C, (long)ldx, (long)ldy, eps);
+    else if (vpl == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, (const h16*)X, gamma, beta, (h16*)Y, (long)rows, C, (long)ldx, (long)ldy, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, (const h16*)X, gamma, beta, (h16*)Y, (long)rows, C, (long)ldx, (long)ldy, eps);
+    pbe_prof_end(PBE_K_LNORM, s, 4.0 * (double)rows * C);
+    PBE_LAUNCH_CHECK("pbe_layernorm_f16");
+    return PBE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax with a scale (VAE mid-block attention scores): one workgroup per row, three
+// sweeps over the row (max, sum, write); the 8-18 KB row stays in L2 between sweeps.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const h16* X, h16* Y, int cols, long ldx, long ldy, float scale_log2e) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const h16* x = X + (long)blockIdx.x * ldx;
+    h16* y = Y + (long)blockIdx.x * ldy;
+    const int nv = cols >> 3;
+    float mx = -INFINITY;
+    for (int v = tid; v < nv; v += 256) {
+        const h16x8 a = *reinterpret_cast<const h16x8*>(x + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)a[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = tid; v < nv; v += 256) {
+        const h16x8 a = *reinterpret_cast<const h16x8*>(x + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((float)a[e] * scale_log2e - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int v = tid; v < nv; v += 256) {
+        const h16x8 a = *reinterpret_cast<const h16x8*>(x + v * 8);
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)(__builtin_amdgcn_exp2f((float)a[e] * scale_log2e - mx) * inv);
+        *reinterpret_cast<h16x8*>(y + v * 8) = o;
+    }
+}
+
+extern "C" int pbe_softmax_rows_f16(const void* X, void* Y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy, float scale,
+                                    pbe_stream_t stream) {
+    PBE_REQUIRE(X && Y && rows > 0 && cols > 0, "pbe_softmax_rows_f16: bad arguments");
+    PBE_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "pbe_softmax_rows_f16: cols / ld must be multiples of 8");
+    PBE_REQUIRE(scale > 0.f, "pbe_softmax_rows_f16: scale must be positive");
+    PBE_REQUIRE(rows < (1L << 31), "pbe_softmax_rows_f16: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    pbe_prof_begin(PBE_K_SOFTMAX, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, (const h16*)X, (h16*)Y, cols, (long)ldx, (long)ldy,
+                       scale * 1.4426950408889634f);
+    pbe_prof_end(PBE_K_SOFTMAX, s, 4.0 * (double)rows * cols);
+    PBE_LAUNCH_CHECK("pbe_softmax_rows_f16");
+    return PBE_OK;
+}

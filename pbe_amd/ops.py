@@ -1,0 +1,365 @@
+"""Tensor-level wrappers over the C-ABI (include/pbe_hip.h).
+
+torch is used for device memory and the current HIP stream only; every arithmetic step is a
+kernel of libpbe_hip.so.  All wrappers raise if handed CPU tensors — there is no fallback.
+Activations are fp16; ``[B, H, W, C]`` / ``[rows, C]`` (channels last, contiguous).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _l
+
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
+_ws = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _l.PbeError(f"{what}: expected a tensor on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _l.PbeError(f"{what}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _h(t, what):
+    return _req(t, torch.float16, what)
+
+
+def _f(t, what):
+    return _req(t, torch.float32, what)
+
+
+def _rows(t: torch.Tensor, what: str) -> Tuple[int, int, int]:
+    """(rows, cols, ld) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _l.PbeError(f"{what}: expected a 2-D tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
+         rowvec: Optional[torch.Tensor] = None, group_rows: int = 0, resid: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         alpha: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, n] = act(alpha * sum_k [a | a2][m, k] w[n, k] + bias + rowvec[m // group_rows, n]) + resid[m, n].
+    2-D operands, or 3-D [batch, rows, cols] for a strided batch (w may have batch 1)."""
+    _h(a, "gemm a"); _h(w, "gemm w")
+    batch = 1
+    sA = sW = sC = sR = 0
+    if a.dim() == 3:
+        batch = a.shape[0]
+        if a.stride(2) != 1 or w.dim() != 3 or w.stride(2) != 1 or w.shape[0] not in (1, batch):
+            raise _l.PbeError("gemm: bad batched operands")
+        M, K, lda, sA = a.shape[1], a.shape[2], a.stride(1), a.stride(0)
+        N, Kw, ldw = w.shape[1], w.shape[2], w.stride(1)
+        sW = w.stride(0) if w.shape[0] == batch else 0
+        if out is None:
+            out = torch.empty((batch, M, N), dtype=torch.float16, device=a.device)
+        ldc, sC = out.stride(1), out.stride(0)
+        ldr = 0
+        if resid is not None:
+            _h(resid, "gemm resid")
+            ldr = resid.stride(-2)
+            sR = resid.stride(0) if (resid.dim() == 3 and resid.shape[0] == batch) else 0
+    else:
+        M, K, lda = _rows(a, "gemm a")
+        N, Kw, ldw = _rows(w, "gemm w")
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float16, device=a.device)
+        ldc = _rows(out, "gemm out")[2]
+        ldr = 0
+        if resid is not None:
+            ldr = _rows(_h(resid, "gemm resid"), "gemm resid")[2]
+    K1, lda2 = K, 0
+    if a2 is not None:
+        _, K2, lda2 = _rows(_h(a2, "gemm a2"), "gemm a2")
+        K = K1 + K2
+    if Kw != K:
+        raise _l.PbeError(f"gemm: K mismatch, activations {K} vs weights {Kw}")
+    if bias is not None:
+        _f(bias, "gemm bias")
+        if bias.numel() != (M if bias_per_row else N):
+            raise _l.PbeError("gemm: bias length mismatch")
+    ldv = 0
+    if rowvec is not None:
+        _h(rowvec, "gemm rowvec")
+        ldv = rowvec.stride(0) if rowvec.dim() == 2 else 0
+        if group_rows <= 0:
+            raise _l.PbeError("gemm: rowvec needs group_rows")
+    d = _l.GemmDesc(_p(a), _p(a2), _p(w), _p(_h(out, "gemm out")), _p(bias), _p(rowvec), _p(resid), M, N, K, K1, lda, lda2, ldw, ldc, ldr,
+                    ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0)
+    _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
+    return out
+
+
+def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool) -> Tuple[int, int]:
+    hv, wv = (h * 2, w * 2) if upsample else (h, w)
+    extra = 2 if pad else 1
+    return (hv + extra - 3) // stride + 1, (wv + extra - 3) // stride + 1
+
+
+def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, x2: Optional[torch.Tensor] = None,
+            rowvec: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1,
+            upsample: bool = False, act: int = ACT_NONE) -> torch.Tensor:
+    """NHWC 3x3 conv on the matrix cores; ``wp`` is the packed [Cout, 9*Cin] weight (pack_conv3x3)."""
+    _h(x, "conv3x3 x"); _h(wp, "conv3x3 w")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise _l.PbeError("conv3x3: x must be a contiguous [B,H,W,C] tensor")
+    B, H, W, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _h(x2, "conv3x3 x2")
+        if x2.dim() != 4 or not x2.is_contiguous() or x2.shape[:3] != x.shape[:3]:
+            raise _l.PbeError("conv3x3: x2 must match x in [B,H,W]")
+        C2 = x2.shape[3]
+    Cout = wp.shape[0]
+    if wp.dim() != 2 or not wp.is_contiguous() or wp.shape[1] != 9 * (C1 + C2):
+        raise _l.PbeError(f"conv3x3: packed weight must be [Cout, {9 * (C1 + C2)}], got {tuple(wp.shape)}")
+    Ho, Wo = conv_out_hw(H, W, stride, pad, upsample)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+    ldv = 0
+    if rowvec is not None:
+        _h(rowvec, "conv3x3 rowvec")
+        if rowvec.dim() != 2 or rowvec.shape[0] != B or rowvec.stride(1) != 1:
+            raise _l.PbeError("conv3x3: rowvec must be [B, >=Cout] with unit inner stride")
+        ldv = rowvec.stride(0)
+    if resid is not None:
+        _h(resid, "conv3x3 resid")
+        if tuple(resid.shape) != tuple(y.shape) or not resid.is_contiguous():
+            raise _l.PbeError("conv3x3: resid must match the output shape")
+    if bias is not None:
+        _f(bias, "conv3x3 bias")
+    d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
+                       1 if upsample else 0, ldv, act)
+    _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
+    return y
+
+
+def conv3x3_small(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, stride: int = 1, pad: int = 1,
+                  act: int = ACT_NONE, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 conv for tiny Cin (channel-padded NHWC input, Cp in {8,16}): im2col + GEMM."""
+    _h(x, "conv3x3_small x")
+    B, H, W, Cp = x.shape
+    Ho, Wo = conv_out_hw(H, W, stride, pad, False)
+    cols = torch.empty((B * Ho * Wo, 9 * Cp), dtype=torch.float16, device=x.device)
+    _l.check(_l.load().pbe_im2col3x3_f16(_p(x), _p(cols), B, H, W, Cp, stride, pad, _stream()), "pbe_im2col3x3_f16")
+    y = gemm(cols, wp, bias, act=act, resid=None if resid is None else resid.reshape(B * Ho * Wo, -1))
+    return y.view(B, Ho, Wo, wp.shape[0])
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, *, x2: Optional[torch.Tensor] = None,
+              groups: int = 32) -> torch.Tensor:
+    """GroupNorm(+SiLU) of NHWC x (optionally the channel concat x | x2); output has C1+C2 channels."""
+    _h(x, "groupnorm x"); _f(gamma, "groupnorm gamma"); _f(beta, "groupnorm beta")
+    if not x.is_contiguous():
+        raise _l.PbeError("groupnorm: x must be contiguous")
+    B, C1 = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _h(x2, "groupnorm x2")
+        C2 = x2.shape[-1]
+        if not x2.is_contiguous() or x2.numel() != B * HW * C2:
+            raise _l.PbeError("groupnorm: x2 shape mismatch")
+    if gamma.numel() != C1 + C2 or beta.numel() != C1 + C2:
+        raise _l.PbeError("groupnorm: affine length mismatch")
+    lib = _l.load()
+    need = lib.pbe_groupnorm_workspace_bytes(B, HW)
+    key = (x.device.index, "gn")
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 21), dtype=torch.uint8, device=x.device)
+        _ws[key] = ws
+    y = torch.empty(tuple(x.shape[:-1]) + (C1 + C2,), dtype=torch.float16, device=x.device)
+    _l.check(lib.pbe_groupnorm_f16(_p(x), _p(x2), _p(gamma), _p(beta), _p(y), B, HW, C1, C2, groups, float(eps), 1 if silu else 0,
+                                   _p(ws), ws.numel(), _stream()), "pbe_groupnorm_f16")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _h(x, "layernorm x"); _f(gamma, "layernorm gamma"); _f(beta, "layernorm beta")
+    x2 = x.reshape(-1, x.shape[-1])
+    rows, Cc, ldx = _rows(x2, "layernorm x")
+    y = torch.empty((rows, Cc), dtype=torch.float16, device=x.device)
+    _l.check(_l.load().pbe_layernorm_f16(_p(x2), _p(gamma), _p(beta), _p(y), rows, Cc, ldx, Cc, float(eps), _stream()), "pbe_layernorm_f16")
+    return y.view(x.shape)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, Nq: int, Nk: int, D: int, scale: float, *,
+              q_strides: Tuple[int, int], k_strides: Tuple[int, int], vt_strides: Tuple[int, int],
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T scale) v -> [B, Nq, H*D].  q/k: element (b,n,h,d) at b*bs + n*rs + h*D + d of the given
+    (possibly sliced) tensors; vt: element (b,h,d,n) at b*bs + (h*D+d)*rs + n.  strides = (bs, rs) in elements."""
+    _h(q, "attention q"); _h(k, "attention k"); _h(vt, "attention vt")
+    if out is None:
+        out = torch.empty((B, Nq, H * D), dtype=torch.float16, device=q.device)
+    d = _l.AttnDesc(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, D, q_strides[0], q_strides[1], k_strides[0], k_strides[1],
+                    vt_strides[0], vt_strides[1], out.stride(0), out.stride(1), float(scale))
+    _l.check(_l.load().pbe_attention_f16(C.byref(d), _stream()), "pbe_attention_f16")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float) -> torch.Tensor:
+    _h(x, "softmax_rows x")
+    x2 = x.reshape(-1, x.shape[-1])
+    rows, cols, ldx = _rows(x2, "softmax_rows x")
+    y = torch.empty((rows, cols), dtype=torch.float16, device=x.device)
+    _l.check(_l.load().pbe_softmax_rows_f16(_p(x2), _p(y), rows, cols, ldx, cols, float(scale), _stream()), "pbe_softmax_rows_f16")
+    return y.view(x.shape)
+
+
+def geglu(h: torch.Tensor) -> torch.Tensor:
+    _h(h, "geglu h")
+    if not h.is_contiguous():
+        raise _l.PbeError("geglu: h must be contiguous")
+    F = h.shape[-1] // 2
+    M = h.numel() // (2 * F)
+    y = torch.empty(tuple(h.shape[:-1]) + (F,), dtype=torch.float16, device=h.device)
+    _l.check(_l.load().pbe_geglu_f16(_p(h), _p(y), M, F, _stream()), "pbe_geglu_f16")
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    _req(t, torch.int64, "timestep_embedding t")
+    t = t.contiguous()
+    y = torch.empty((t.shape[0], dim), dtype=torch.float16, device=t.device)
+    _l.check(_l.load().pbe_timestep_embedding_f16(_p(t), _p(y), t.shape[0], dim, float(max_period), _stream()), "pbe_timestep_embedding_f16")
+    return y
+
+
+def nchw_to_nhwc(x: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
+    """fp32 NCHW -> fp16 NHWC with the channel dim zero-padded to cp."""
+    _f(x, "nchw_to_nhwc x")
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    cp = Cc if cp is None else cp
+    y = torch.empty((B, H, W, cp), dtype=torch.float16, device=x.device)
+    _l.check(_l.load().pbe_nchw_f32_to_nhwc_f16(_p(x), _p(y), B, Cc, H * W, cp, _stream()), "pbe_nchw_f32_to_nhwc_f16")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    """fp16 NHWC [B,H,W,ld] -> fp32 NCHW of the first c channels."""
+    _h(x, "nhwc_to_nchw x")
+    if not x.is_contiguous():
+        raise _l.PbeError("nhwc_to_nchw: x must be contiguous")
+    B, H, W, ld = x.shape
+    c = ld if c is None else c
+    y = torch.empty((B, c, H, W), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pbe_nhwc_f16_to_nchw_f32(_p(x), _p(y), B, c, H * W, ld, _stream()), "pbe_nhwc_f16_to_nchw_f32")
+    return y
+
+
+def plms_pack_input(x: torch.Tensor, z_inpaint: torch.Tensor, mask: torch.Tensor, dup: int) -> torch.Tensor:
+    _f(x, "plms x"); _f(z_inpaint, "plms z_inpaint"); _f(mask, "plms mask")
+    B, _, H, W = x.shape
+    if tuple(z_inpaint.shape) != (B, 4, H, W) or tuple(mask.shape) != (B, 1, H, W):
+        raise _l.PbeError(f"plms_pack_input: shape mismatch x={tuple(x.shape)} z={tuple(z_inpaint.shape)} mask={tuple(mask.shape)}")
+    x9 = torch.empty((dup * B, H, W, 16), dtype=torch.float16, device=x.device)
+    _l.check(_l.load().pbe_plms_pack_input(_p(x.contiguous()), _p(z_inpaint.contiguous()), _p(mask.contiguous()), _p(x9), B, H * W, dup,
+                                           _stream()), "pbe_plms_pack_input")
+    return x9
+
+
+def plms_update(eps_out: torch.Tensor, dup: int, cfg_scale: float, x: torch.Tensor, hist, coef8, want_e_t: bool = True,
+                want_pred: bool = True):
+    """Fused CFG combine + multistep weights + x_prev / pred_x0 (plms.py:188-189, 202-219, 230-244)."""
+    _h(eps_out, "plms eps_out"); _f(x, "plms x")
+    B, _, H, W = x.shape
+    ld = eps_out.shape[-1]
+    e_t = torch.empty_like(x) if want_e_t else None
+    pred = torch.empty_like(x) if want_pred else None
+    x_prev = torch.empty_like(x)
+    h = [None, None, None]
+    for i, t in enumerate(hist[:3]):
+        h[i] = _f(t, "plms history")
+    arr = (C.c_float * 8)(*[float(v) for v in coef8])
+    _l.check(_l.load().pbe_plms_update(_p(eps_out), ld, dup, float(cfg_scale), _p(x), _p(h[0]), _p(h[1]), _p(h[2]), arr, _p(e_t),
+                                       _p(x_prev), _p(pred), B, H * W, _stream()), "pbe_plms_update")
+    return x_prev, pred, e_t
+
+
+def posterior_sample(moments: torch.Tensor, eps: torch.Tensor, scale: float) -> torch.Tensor:
+    _h(moments, "posterior moments"); _f(eps, "posterior eps")
+    B, H, W, ld = moments.shape
+    z = torch.empty((B, 4, H, W), dtype=torch.float32, device=moments.device)
+    _l.check(_l.load().pbe_posterior_sample(_p(moments), ld, _p(eps.contiguous()), _p(z), B, H * W, float(scale), _stream()), "pbe_posterior_sample")
+    return z
+
+
+def scale_latent(z: torch.Tensor, inv_scale: float) -> torch.Tensor:
+    _f(z, "scale_latent z")
+    z = z.contiguous()
+    B, Cc, H, W = z.shape
+    y = torch.empty((B, H, W, 8), dtype=torch.float16, device=z.device)
+    _l.check(_l.load().pbe_scale_latent_f16(_p(z), _p(y), B, Cc, H * W, float(inv_scale), _stream()), "pbe_scale_latent_f16")
+    return y
+
+
+def image_post(x: torch.Tensor) -> torch.Tensor:
+    _h(x, "image_post x")
+    B, H, W, ld = x.shape
+    y = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pbe_image_post_f32(_p(x), _p(y), B, H * W, ld, _stream()), "pbe_image_post_f32")
+    return y
+
+
+def clip_patchify(pixels: torch.Tensor, patch: int, kp: int) -> torch.Tensor:
+    _f(pixels, "clip_patchify pixels")
+    pixels = pixels.contiguous()
+    B, _, S, _ = pixels.shape
+    g = S // patch
+    y = torch.empty((B * g * g, kp), dtype=torch.float16, device=pixels.device)
+    _l.check(_l.load().pbe_clip_patchify_f16(_p(pixels), _p(y), B, S, patch, kp, _stream()), "pbe_clip_patchify_f16")
+    return y
+
+
+def bcast_row(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, B: int, y_bs: int) -> None:
+    """out[bi * y_bs + c] = a[c] + b[c] for bi < B."""
+    _h(a, "bcast_row a"); _h(b, "bcast_row b"); _h(out, "bcast_row out")
+    _l.check(_l.load().pbe_bcast_row_f16(_p(a), _p(b), _p(out), B, a.numel(), y_bs, _stream()), "pbe_bcast_row_f16")
+
+
+# ---- weight packing (one-off, at load time) ---------------------------------------------------
+def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """OIHW fp32 -> [Cout, 9*Cin] fp16, k = (ky*3+kx)*Cin + ci (optionally zero-padding Cin)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    wp = w.permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad != ci:
+        wp = torch.nn.functional.pad(wp, (0, cin_pad - ci))
+    return wp.reshape(co, -1).to(torch.float16).contiguous()
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    return w.reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+# ---- profiling --------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    _l.load().pbe_prof_enable(1 if on else 0)
+
+
+def prof_reset() -> None:
+    _l.load().pbe_prof_reset()
+
+
+def prof_collect():
+    lib = _l.load()
+    buf = (C.c_double * (3 * 16))()
+    n = lib.pbe_prof_collect(buf, 16)
+    out = {}
+    for k in range(n):
+        out[lib.pbe_prof_class_name(k).decode()] = {"launches": int(buf[3 * k]), "ms": buf[3 * k + 1], "work": buf[3 * k + 2]}
+    return out

@@ -1,0 +1,318 @@
+"""Per-kernel parity on the GPU, through the C-ABI (pbe_amd.ops -> libpbe_hip.so), against plain
+fp32 torch on the CPU evaluated on the SAME fp16-rounded inputs.
+
+Tolerances (stated, fp16 I/O with fp32 accumulation): an output element may differ from the
+fp32 result by fp16 rounding of the result (2^-11 relative) plus accumulation-order noise, so
+we require  max|d| <= 2e-3 * max|ref| + 1e-3  per op unless a test says otherwise.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rtol=2e-3, atol=1e-3, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    lim = rtol * ref.abs().max().item() + atol
+    assert err <= lim, f"{what}: max|d|={err:.4e} > {lim:.4e}"
+
+
+def _h(t, dev):
+    return t.to(torch.float16).to(dev)
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_gemm_integer_layout_exact(dev):
+    """A = small asymmetric integers: exact in fp16/fp32, so any fragment-layout error shows as a
+    wrong integer (cdna guide: check MFMA maps with exact, asymmetric data)."""
+    from pbe_amd import ops
+    M, N, K = 192, 160, 128
+    a = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+    w = ((torch.arange(N * K).reshape(N, K) * 5) % 11 - 5).float()
+    ref = a @ w.t()
+    got = ops.gemm(_h(a, dev), _h(w, dev))
+    assert torch.equal(got.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 320, 768), (8, 1280, 320), (1024, 2560, 320), (300, 4, 2880),
+                                   (96, 72, 72), (4096, 64, 128), (64, 64, 8)])
+def test_gemm_shapes(dev, M, N, K):
+    from pbe_amd import ops
+    g = _g(M * 7 + N)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    bias = torch.randn(N, generator=g)
+    ref = a.float() @ w.float().t() + bias
+    got = ops.gemm(a.to(dev), w.to(dev), bias.to(dev))
+    _close(got, ref, what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogue(dev, act):
+    from pbe_amd import ops
+    g = _g(act)
+    M, N, K, G = 384, 320, 256, 128
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    bias = torch.randn(N, generator=g)
+    rv = torch.randn(M // G, N, generator=g).half()
+    res = torch.randn(M, N, generator=g).half()
+    pre = 0.5 * (a.float() @ w.float().t()) + bias + rv.float().repeat_interleave(G, 0)
+    fn = {0: lambda v: v, 1: F.silu, 2: F.gelu, 3: lambda v: v * torch.sigmoid(1.702 * v)}[act]
+    ref = fn(pre).half().float() + res.float()
+    got = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), rowvec=rv.to(dev), group_rows=G, resid=res.to(dev), act=act, alpha=0.5)
+    _close(got, ref, what=f"gemm epilogue act={act}")
+
+
+def test_gemm_split_k_sources_and_bias_per_row(dev):
+    from pbe_amd import ops
+    g = _g(5)
+    M, N, K1, K2 = 200, 136, 128, 192
+    a1 = torch.randn(M, K1, generator=g).half()
+    a2 = torch.randn(M, K2, generator=g).half()
+    w = (torch.randn(N, K1 + K2, generator=g) / 16).half()
+    bias = torch.randn(M, generator=g)
+    ref = torch.cat([a1, a2], 1).float() @ w.float().t() + bias[:, None]
+    got = ops.gemm(a1.to(dev), w.to(dev), bias.to(dev), a2=a2.to(dev), bias_per_row=True)
+    _close(got, ref, what="gemm split-K sources")
+
+
+def test_gemm_batched_strided(dev):
+    from pbe_amd import ops
+    g = _g(6)
+    Bt, M, N, K = 3, 130, 264, 64
+    a = torch.randn(Bt, M, K, generator=g).half()
+    w = (torch.randn(Bt, N, K, generator=g) / 8).half()
+    ref = torch.bmm(a.float(), w.float().transpose(1, 2))
+    got = ops.gemm(a.to(dev), w.to(dev))
+    _close(got, ref, what="gemm batched")
+    # strided views: columns sliced out of a fused buffer (lda > K)
+    buf = torch.randn(M, 3 * K, generator=g).half()
+    w2 = (torch.randn(N, K, generator=g) / 8).half()
+    got2 = ops.gemm(buf.to(dev)[:, K:2 * K], w2.to(dev))
+    _close(got2, buf[:, K:2 * K].float() @ w2.float().t(), what="gemm strided A")
+
+
+# ---------------------------------------------------------------------------------------------
+def _conv_ref(x, w, b, stride, pad, ups, x2=None):
+    xx = x if x2 is None else torch.cat([x, x2], -1)
+    xx = xx.float().permute(0, 3, 1, 2)
+    if ups:
+        xx = F.interpolate(xx, scale_factor=2, mode="nearest")
+    if pad == 0:
+        xx = F.pad(xx, (0, 1, 0, 1))
+    y = F.conv2d(xx, w.float(), b, stride=stride, padding=1 if pad else 0)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,pad,ups", [
+    (2, 16, 16, 64, 128, 1, 1, False), (1, 12, 20, 128, 64, 1, 1, False), (2, 16, 16, 64, 64, 2, 1, False),
+    (2, 16, 16, 64, 64, 2, 0, False), (2, 8, 8, 128, 128, 1, 1, True), (3, 9, 7, 192, 320, 1, 1, False),
+    (1, 64, 64, 320, 320, 1, 1, False)])
+def test_conv3x3(dev, B, H, W, Ci, Co, stride, pad, ups):
+    from pbe_amd import ops
+    g = _g(H * 31 + Ci)
+    x = torch.randn(B, H, W, Ci, generator=g).half()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).half()
+    b = torch.randn(Co, generator=g)
+    ref = _conv_ref(x, w, b, stride, pad, ups)
+    got = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w.float()).to(dev), b.to(dev), stride=stride, pad=pad, upsample=ups)
+    _close(got, ref, what=f"conv3x3 {B}x{H}x{W}x{Ci}->{Co} s{stride} p{pad} u{ups}")
+
+
+def test_conv3x3_concat_rowvec_resid(dev):
+    from pbe_amd import ops
+    g = _g(9)
+    B, H, W, C1, C2, Co = 2, 16, 16, 128, 64, 128
+    x1 = torch.randn(B, H, W, C1, generator=g).half()
+    x2 = torch.randn(B, H, W, C2, generator=g).half()
+    w = (torch.randn(Co, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2))).half()
+    b = torch.randn(Co, generator=g)
+    emb = torch.randn(B, Co + 64, generator=g).half()          # rowvec taken as a column slice of a wider buffer
+    res = torch.randn(B, H, W, Co, generator=g).half()
+    ref = (_conv_ref(x1, w, b, 1, 1, False, x2) + emb[:, 64:].float()[:, None, None, :]).half().float() + res.float()
+    got = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w.float()).to(dev), b.to(dev), x2=x2.to(dev), rowvec=emb.to(dev)[:, 64:], resid=res.to(dev))
+    _close(got, ref, what="conv3x3 concat+emb+resid")
+
+
+def test_conv3x3_small_cin(dev):
+    from pbe_amd import ops
+    g = _g(10)
+    B, H, W, Ci, Co = 2, 16, 16, 9, 64
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / 9).half()
+    b = torch.randn(Co, generator=g)
+    xh = ops.nchw_to_nhwc(x.to(dev), 16)
+    ref = F.conv2d(x.half().float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3_small(xh, ops.pack_conv3x3(w.float(), 16).to(dev), b.to(dev))
+    _close(got, ref, what="conv3x3 small Cin")
+    back = ops.nhwc_to_nchw(xh, 9)
+    assert torch.equal(back.cpu(), x.half().float())
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,C,silu,eps", [(2, 256, 320, True, 1e-5), (3, 64, 64, False, 1e-6), (2, 64, 2560, True, 1e-5),
+                                              (1, 4096, 128, True, 1e-6), (2, 1000, 960, True, 1e-5), (1, 65536, 128, True, 1e-6)])
+def test_groupnorm(dev, B, HW, C, silu, eps):
+    from pbe_amd import ops
+    g = _g(C + HW)
+    x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).half()
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, gamma, beta, eps).transpose(1, 2)
+    ref = F.silu(ref) if silu else ref
+    got = ops.groupnorm(x.to(dev), gamma.to(dev), beta.to(dev), eps, silu)
+    _close(got, ref, rtol=3e-3, what=f"groupnorm C={C} HW={HW}")
+
+
+def test_groupnorm_concat(dev):
+    from pbe_amd import ops
+    g = _g(77)
+    B, HW, C1, C2 = 2, 256, 640, 320
+    x1 = torch.randn(B, HW, C1, generator=g).half()
+    x2 = (torch.randn(B, HW, C2, generator=g) * 3).half()
+    gamma, beta = 1 + 0.1 * torch.randn(C1 + C2, generator=g), 0.1 * torch.randn(C1 + C2, generator=g)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], -1).float().transpose(1, 2), 32, gamma, beta, 1e-5)).transpose(1, 2)
+    got = ops.groupnorm(x1.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True, x2=x2.to(dev))
+    _close(got, ref, rtol=3e-3, what="groupnorm concat")
+
+
+@pytest.mark.parametrize("rows,C", [(100, 320), (257, 1024), (33, 1280), (7, 64), (5, 2048)])
+def test_layernorm(dev, rows, C):
+    from pbe_amd import ops
+    g = _g(C)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).half()
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    got = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
+    _close(got, ref, rtol=3e-3, what=f"layernorm C={C}")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,N,D", [(2, 8, 256, 40), (1, 8, 1024, 40), (2, 8, 256, 80), (2, 8, 64, 160), (1, 16, 257, 64),
+                                      (2, 8, 256, 8), (2, 4, 130, 32), (1, 2, 64, 16), (1, 8, 4096, 40), (1, 3, 200, 128)])
+def test_attention(dev, B, H, N, D):
+    from pbe_amd import ops
+    g = _g(N + D)
+    Cc = H * D
+    qk = torch.randn(B, N, 2 * Cc, generator=g).half()          # fused [q | k] buffer, as the projection GEMM writes it
+    v = torch.randn(B, N, Cc, generator=g).half()
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, npad, dtype=torch.float16)
+    vt[:, :, :N] = v.transpose(1, 2)
+    scale = D ** -0.5
+    q4 = qk[..., :Cc].float().reshape(B, N, H, D).transpose(1, 2)
+    k4 = qk[..., Cc:].float().reshape(B, N, H, D).transpose(1, 2)
+    v4 = v.float().reshape(B, N, H, D).transpose(1, 2)
+    ref = torch.softmax(q4 @ k4.transpose(-1, -2) * scale, -1) @ v4
+    ref = ref.transpose(1, 2).reshape(B, N, Cc)
+    qkd, vtd = qk.to(dev), vt.to(dev)
+    got = ops.attention(qkd, qkd[..., Cc:], vtd, B, H, N, N, D, scale, q_strides=(N * 2 * Cc, 2 * Cc), k_strides=(N * 2 * Cc, 2 * Cc),
+                        vt_strides=(Cc * npad, npad))
+    _close(got, ref, rtol=4e-3, atol=2e-3, what=f"attention B{B} H{H} N{N} D{D}")
+
+
+def test_attention_softmax_spike(dev):
+    """Force the online-softmax rescale: one key row aligned with a query so the running max jumps late."""
+    from pbe_amd import ops
+    B, H, N, D = 1, 2, 320, 40
+    g = _g(3)
+    q = torch.randn(B, N, H * D, generator=g).half()
+    k = torch.randn(B, N, H * D, generator=g).half()
+    k[0, 300] = (q[0, 17].float() * 4).half()
+    v = torch.randn(B, N, H * D, generator=g).half()
+    vt = v.transpose(1, 2).contiguous()
+    scale = D ** -0.5
+    q4, k4, v4 = (t.float().reshape(B, N, H, D).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(q4 @ k4.transpose(-1, -2) * scale, -1) @ v4).transpose(1, 2).reshape(B, N, H * D)
+    got = ops.attention(q.to(dev), k.to(dev), vt.to(dev), B, H, N, N, D, scale, q_strides=(N * H * D, H * D), k_strides=(N * H * D, H * D),
+                        vt_strides=(H * D * N, N))
+    _close(got, ref, rtol=4e-3, atol=2e-3, what="attention spike")
+
+
+def test_softmax_rows_and_geglu(dev):
+    from pbe_amd import ops
+    g = _g(12)
+    x = (torch.randn(300, 4096, generator=g) * 4).half()
+    got = ops.softmax_rows(x.to(dev), 0.37)
+    _close(got, torch.softmax(x.float() * 0.37, -1), rtol=3e-3, atol=1e-6, what="softmax_rows")
+    h = torch.randn(130, 2 * 1280, generator=g).half()
+    a, gate = h.float().chunk(2, -1)
+    _close(ops.geglu(h.to(dev)), a * F.gelu(gate), what="geglu")
+
+
+def test_timestep_embedding(dev, golden_dir):
+    import numpy as np
+    from pbe_amd import ops
+    gold = np.load(f"{golden_dir}/primitives.npz")
+    got = ops.timestep_embedding(torch.from_numpy(gold["temb_t"]).to(dev), 320)
+    _close(got, torch.from_numpy(gold["temb"]), rtol=1e-3, atol=2e-3, what="timestep_embedding vs reference golden")
+
+
+def test_plms_kernels(dev):
+    from pbe_amd import ops
+    g = _g(21)
+    B, H, W = 2, 16, 16
+    x, z, m = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g), torch.rand(B, 1, H, W, generator=g)
+    x9 = ops.plms_pack_input(x.to(dev), z.to(dev), m.to(dev), 2).float().cpu()
+    ref = torch.cat([x, z, m], 1).permute(0, 2, 3, 1).half().float()
+    assert torch.equal(x9[:B, ..., :9], ref) and torch.equal(x9[B:, ..., :9], ref) and (x9[..., 9:] == 0).all()
+    eps = torch.randn(2 * B, H, W, 8, generator=g).half()
+    h1, h2, h3 = (torch.randn(B, 4, H, W, generator=g) for _ in range(3))
+    coef = [55 / 24, -59 / 24, 37 / 24, -9 / 24, 0.6, 1.25, 0.9, 0.43]
+    e_u, e_c = eps[:B, ..., :4].float().permute(0, 3, 1, 2), eps[B:, ..., :4].float().permute(0, 3, 1, 2)
+    e = e_u + 5.0 * (e_c - e_u)
+    ep = coef[0] * e + coef[1] * h1 + coef[2] * h2 + coef[3] * h3
+    px0 = (x - coef[4] * ep) * coef[5]
+    xp = coef[6] * px0 + coef[7] * ep
+    gx, gp, ge = ops.plms_update(eps.to(dev), 2, 5.0, x.to(dev), [h1.to(dev), h2.to(dev), h3.to(dev)], coef)
+    _close(ge, e, rtol=1e-5, atol=1e-5, what="plms e_t")
+    _close(gp, px0, rtol=1e-5, atol=1e-5, what="plms pred_x0")
+    _close(gx, xp, rtol=1e-5, atol=1e-5, what="plms x_prev")
+
+
+def test_posterior_latent_image_kernels(dev):
+    from pbe_amd import ops
+    g = _g(22)
+    B, H, W = 2, 8, 8
+    mom = (torch.randn(B, H, W, 8, generator=g) * 3).half()
+    eps = torch.randn(B, 4, H, W, generator=g)
+    mean, logvar = mom.float()[..., :4].permute(0, 3, 1, 2), mom.float()[..., 4:].permute(0, 3, 1, 2)
+    ref = 0.18215 * (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * eps)
+    _close(ops.posterior_sample(mom.to(dev), eps.to(dev), 0.18215), ref, rtol=1e-5, atol=1e-5, what="posterior")
+    z = torch.randn(B, 9, H, W, generator=g)
+    zl = ops.scale_latent(z.to(dev), 1 / 0.18215).float().cpu()
+    assert torch.equal(zl[..., :4], (z[:, :4] / 0.18215 if False else (z[:, :4] * (1 / 0.18215))).permute(0, 2, 3, 1).half().float())
+    assert (zl[..., 4:] == 0).all()
+    img = (torch.randn(B, H, W, 8, generator=g) * 2).half()
+    _close(ops.image_post(img.to(dev)), ((img.float()[..., :3] + 1) / 2).clamp(0, 1).permute(0, 3, 1, 2), rtol=1e-6, atol=1e-6, what="image_post")
+
+
+def test_clip_patchify(dev):
+    from pbe_amd import ops
+    g = _g(23)
+    px = torch.randn(2, 3, 224, 224, generator=g)
+    got = ops.clip_patchify(px.to(dev), 14, 592).float().cpu()
+    ref = F.unfold(px, 14, stride=14).transpose(1, 2).reshape(2 * 256, 588).half().float()
+    assert torch.equal(got[:, :588], ref) and (got[:, 588:] == 0).all()
+
+
+def test_errors_are_loud(dev):
+    from pbe_amd import ops
+    from pbe_amd.lib import PbeError
+    with pytest.raises(PbeError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16))      # CPU tensors
+    with pytest.raises(PbeError):
+        ops.gemm(torch.zeros(8, 12, dtype=torch.float16, device=dev), torch.zeros(8, 12, dtype=torch.float16, device=dev))  # K % 8
+    with pytest.raises(PbeError):
+        ops.conv3x3(torch.zeros(1, 4, 4, 9, dtype=torch.float16, device=dev), torch.zeros(8, 81, dtype=torch.float16, device=dev), None)
