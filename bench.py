@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — Paint-by-Example PLMS hot path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic 512x512 triples per GPU:
+CLIP exemplar encode + VAE encode + 50 PLMS steps (51 U-Net calls at batch 2B under classifier-free
+guidance, scale 5) + VAE decode.  Inputs (image / mask / exemplar / x_T / posterior
+noise) are resident in HBM before the timed region.  Weights: name-seeded random init of the
+configs/v1.yaml architecture (no checkpoint exists offline).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (driver, N > 1)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     dominant kernel class (3x3-conv implicit GEMM, MFMA-bound): algorithmic FLOP per
+               launch / average launch duration, measured with HIP events on the launch stream in a
+               separate profiled pass AFTER the timed region (pbe_prof_*), against 2.5 PFLOP/s dense fp16.
+  cpu_baseline the CPU oracle (a port: oracle/pbe_oracle.py, fp32 torch) timed on this box's host
+               cores on a bounded sample (1 CFG U-Net pair + VAE enc/dec + CLIP for one image),
+               extrapolated to images/sec.  Rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_IMAGE = 85.08e12          # 51*2*796.94 + 1116.7 + 2514.5 + 155.5 + 0.13 GFLOP
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def build_model(device, rank, world):
+    """Rank 0 synthesises the weights; other ranks allocate empty storage and receive them through
+    ONE bucketed RCCL broadcast."""
+    from ldm.util import instantiate_from_config, load_yaml_config
+    from pbe_amd.shard import broadcast_weights_
+    from pbe_amd.weights import fill_latent_diffusion_
+    cfg = load_yaml_config(os.path.join(ROOT, "configs", "v1.yaml"))["model"]
+    cpu_sd = None
+    t0 = time.time()
+    if rank == 0:
+        model = instantiate_from_config(cfg)
+        fill_latent_diffusion_(model)
+        if world == 1:
+            cpu_sd = {k: v for k, v in model.state_dict().items()}      # fp32 CPU copy for the oracle baseline
+        model = model.to(device).eval()
+    else:
+        with torch.device("meta"):
+            model = instantiate_from_config(cfg)
+        model = model.to_empty(device=device).eval()
+        model.register_schedule(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+        model = model.to(device)
+    log(f"model built in {time.time() - t0:.1f}s")
+    if world > 1:
+        t0 = time.time()
+        info = broadcast_weights_(model, src=0)
+        torch.cuda.synchronize()
+        log(f"weight broadcast: {info['bytes'] / 1e9:.2f} GB in {int(info['messages'])} messages, {time.time() - t0:.2f}s")
+    model.prepare()
+    return model, cpu_sd
+
+
+def cpu_baseline(cpu_sd, threads):
+    """Time the oracle (fp32 torch restatement of the reference) on the host: bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pbe_oracle as O
+    import cases
+    torch.set_num_threads(threads)
+    inp = cases.synthetic_triples(1, 512)
+    with torch.no_grad():
+        t0 = time.time()
+        c = O.learned_conditioning(cpu_sd, inp["ref"])
+        t_clip = time.time() - t0
+        t0 = time.time()
+        z = O.first_stage_encode(cpu_sd, inp["image"] * inp["mask"], inp["post_eps"], prefix="first_stage_model.")
+        t_enc = time.time() - t0
+        x9 = torch.cat([inp["x_T"], z, O.resize_mask(inp["mask"], (64, 64))], 1)
+        ctx = torch.cat([cpu_sd["learnable_vector"].float(), c])
+        t0 = time.time()
+        O.unet_forward(cpu_sd, torch.cat([x9] * 2), torch.full((2,), 981, dtype=torch.int64), ctx, prefix="model.diffusion_model.")
+        t_pair = time.time() - t0
+        t0 = time.time()
+        O.first_stage_decode(cpu_sd, inp["x_T"] * 0.18215, prefix="first_stage_model.")
+        t_dec = time.time() - t0
+    per_image = 51 * t_pair + t_enc + t_dec + t_clip
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 CFG U-Net pair ({t_pair:.2f}s) + VAE encode ({t_enc:.2f}s) + decode ({t_dec:.2f}s) + CLIP+mapper ({t_clip:.2f}s) "
+                      f"for one 512x512 image, fp32 oracle; extrapolated x51 U-Net pairs",
+            "unet_s_per_step_per_image": t_pair}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE config #2: 4)")
+    ap.add_argument("--plms-steps", type=int, default=50)
+    ap.add_argument("--scale", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
+
+    import cases
+    from pbe_amd import ops
+    from pbe_amd.pipeline import inpaint
+    from pbe_amd.shard import gather_images
+
+    model, cpu_sd = build_model(device, rank, world)
+    B = a.batch
+    inp = {k: v.to(device) for k, v in cases.synthetic_triples(B, 512, first_index=rank * B).items()}      # resident in HBM
+
+    def one_step(timings=None):
+        out = inpaint(model, inp["image"], inp["mask"], inp["ref"], steps=a.plms_steps, scale=a.scale, x_T=inp["x_T"],
+                      post_eps=inp["post_eps"], timings=timings)
+        u8 = (out["image"] * 255.0).round().to(torch.uint8)
+        return gather_images(u8) if world > 1 else u8
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            one_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- separate passes (outside the timed region): stage split and per-kernel-class events ----
+        stage = {}
+        one_step(timings=stage)
+        prof = None
+        if not a.no_profile:
+            ops.prof_reset()
+            ops.prof_enable(True)
+            one_step()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+            prof = ops.prof_collect()
+            ops.prof_reset()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    images = world * B * a.steps
+    value = images / elapsed
+    line = {
+        "metric": "512x512 images/sec @50 PLMS steps scale=5", "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batch=4/GPU, 512x512, 50 PLMS steps (51 U-Net calls at batch 8), scale=5, fp16 "
+                               "activations + fp32 accumulate, name-seeded random-init U-Net + VAE + CLIP ViT-L/14 weights",
+                   "per_gpu_batch": B, "global_batch": world * B, "plms_steps": a.plms_steps, "cfg_scale": a.scale,
+                   "parallelism": f"batch-sharded x{world}, no per-step collective"},
+        "unet_ms_per_step_per_image": stage.get("sampler_ms", 0.0) / a.plms_steps / B,
+        "stage_ms_per_batch": stage,
+        "e2e_mfma_frac": value / world * FLOP_PER_IMAGE / (MFMA_PEAK_TFLOPS * 1e12),
+    }
+    if prof:
+        conv = prof["conv3x3_igemm"]
+        tf = conv["work"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<*,*,1> (3x3 conv implicit GEMM)", "achieved": tf, "peak": MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "launches": conv["launches"],
+                            "avg_launch_us": 1e3 * conv["ms"] / max(1, conv["launches"]),
+                            "avg_gflop_per_launch": conv["work"] / max(1, conv["launches"]) / 1e9}
+        line["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                      "rate": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                                      "rate_unit": "TFLOP/s" if k in ("conv3x3_igemm", "gemm", "attention") else "TB/s"} for k, v in prof.items()}
+    if world == 1 and not a.no_cpu_baseline and cpu_sd is not None:
+        try:
+            line["cpu_baseline"] = cpu_baseline(cpu_sd, max(1, os.cpu_count() or 1))
+        except Exception as e:                                              # noqa: BLE001
+            line["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

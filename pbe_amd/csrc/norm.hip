@@ -21,16 +21,17 @@ __device__ __forceinline__ const h16* gn_src(const h16* X, const h16* X2, int C1
 
 __global__ void __launch_bounds__(256) gn_stats_kernel(const h16* X, const h16* X2, float* part, int HW, int C1, int C2,
                                                         int groups, int rows_per_block, int TX, int TY) {
+    // Deterministic reduction (bit-identical run to run): per-thread partials go to LDS and are
+    // summed over ty in a fixed order; no atomics.
     __shared__ float s_sum[GN_MAX_C], s_sq[GN_MAX_C];
+    __shared__ float s_pa[256 * 8], s_pq[256 * 8];
     const int C = C1 + C2, C8 = C >> 3, cg = C / groups;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int r0 = chunk * rows_per_block;
     const int r1 = min(HW, r0 + rows_per_block);
     if (ty < TY) {
-        for (int v = tx; v < C8; v += TX) {
+        for (int v = tx; v < C8; v += TX) {            // TY > 1 implies C8 == TX: exactly one pass
             float a[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
@@ -39,11 +40,25 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const h16* X, const h16* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; a[e] += f; q[e] += f * f; }
             }
+            if (TY == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[v * 8 + e], a[e]); atomicAdd(&s_sq[v * 8 + e], q[e]); }
+                for (int e = 0; e < 8; ++e) { s_sum[v * 8 + e] = a[e]; s_sq[v * 8 + e] = q[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s_pa[tid * 8 + e] = a[e]; s_pq[tid * 8 + e] = q[e]; }
+            }
         }
     }
     __syncthreads();
+    if (TY > 1) {
+        for (int c = tid; c < C; c += 256) {
+            const int v = c >> 3, e = c & 7;
+            float a = 0.f, q = 0.f;
+            for (int y = 0; y < TY; ++y) { a += s_pa[(y * TX + v) * 8 + e]; q += s_pq[(y * TX + v) * 8 + e]; }
+            s_sum[c] = a; s_sq[c] = q;
+        }
+        __syncthreads();
+    }
     if (tid < groups) {
         float a = 0.f, q = 0.f;
         for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += s_sum[c]; q += s_sq[c]; }

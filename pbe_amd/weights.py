@@ -57,6 +57,24 @@ def fill_module_(module: torch.nn.Module, seed: int = 0, prefix: str = "") -> No
     module.load_state_dict(new, strict=True)
 
 
+SCHEDULE_BUFFERS = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                    "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                    "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "logvar")
+
+
+def fill_latent_diffusion_(model: torch.nn.Module, seed: int = 0) -> None:
+    """Name-seeded weights for a whole LatentDiffusion (schedule buffers are left as computed)."""
+    sd = model.state_dict()
+    new = {k: synth_tensor(k, v.shape, seed).to(v.dtype) for k, v in sd.items() if k not in SCHEDULE_BUFFERS}
+    torch.nn.Module.load_state_dict(model, new, strict=False)
+    if hasattr(model, "invalidate_packs"):
+        model.invalidate_packs()
+    for m in model.modules():
+        if hasattr(m, "invalidate_packs"):
+            m.invalidate_packs()
+    model.__dict__["_proj_pack"] = None
+
+
 # --- checkpoint key handling (scripts/inference.py:58-75, ddpm.py:245-260) -------------------
 
 _CLIP_OLD = "cond_stage_model.transformer.vision_model."
