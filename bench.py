@@ -202,7 +202,7 @@ def main():
                                       "rate_unit": "TFLOP/s" if k in ("conv3x3_igemm", "gemm", "attention") else "TB/s"} for k, v in prof.items()}
     if world == 1 and not a.no_cpu_baseline and cpu_sd is not None:
         try:
-            line["cpu_baseline"] = cpu_baseline(cpu_sd, max(1, os.cpu_count() or 1))
+            line["cpu_baseline"] = cpu_baseline(cpu_sd, max(1, min(16, os.cpu_count() or 1)))     # a 1-GPU box owns a 16-core share of the host
         except Exception as e:                                              # noqa: BLE001
             line["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
     print(json.dumps(line), flush=True)

@@ -80,6 +80,10 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # torch bundles its own libamdhip64; import it FIRST so libpbe_hip.so binds to the HIP runtime
+        # that owns torch's device context and streams (loading ours first leaves two runtimes in
+        # the process and launches fail with "no ROCm-capable device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise PbeError(f"{LIB_PATH} not found: build it with `python -m pbe_amd.build` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-import build
+import modelbuild as build
 import cases
 
 pytestmark = pytest.mark.gpu
