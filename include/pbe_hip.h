@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 1
+#define PBE_ABI_VERSION 3
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -73,6 +73,9 @@ typedef struct pbe_gemm_desc {
     float alpha;
     int32_t act;
     int32_t bias_per_row;
+    void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
+    size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; 0..6 = block-tile config from a tuning table */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 
@@ -100,6 +103,9 @@ typedef struct pbe_conv3x3_desc {
     int32_t stride, pad, upsample;
     int32_t ldv;
     int32_t act;
+    void* workspace;        /* optional split-K scratch, as in pbe_gemm_desc */
+    size_t workspace_bytes;
+    int32_t tile_cfg;       /* -1 = heuristic, else tile config index (tuning table) */
 } pbe_conv3x3_desc;
 int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
 
@@ -204,6 +210,11 @@ int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t B, int32_t 
 
 /* pbe_image_post_f32 — scripts/inference.py:347: clamp((x+1)/2, 0, 1) of fp16 NHWC [B,HW,ld] -> fp32 NCHW [B,3,HW]. */
 int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32_t ld, pbe_stream_t stream);
+
+/* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
+ * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1).
+ */
+int pbe_tune(int32_t key, int32_t value);
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ---- */
 int pbe_prof_enable(int32_t on);

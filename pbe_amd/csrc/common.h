@@ -63,4 +63,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// activation on a register quad with ONE uniform branch per quad (keeps unrolled epilogues small)
+__device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
+    if (act == 1 || act == 3) {
+        const float k = act == 1 ? 1.0f : 1.702f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-k * v[r]));
+    } else if (act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+    }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -5,16 +5,25 @@
 //                                                          optional fused nearest-2x upsample and
 //                                                          two-source channel concat
 //
-// Tiling (CDNA4, wave64): 256 threads = 4 waves as 2(m) x 2(n); block tile BM x BN x 64;
-// each wave owns (BM/2) x (BN/2) as 16x16 MFMA tiles of v_mfma_f32_16x16x32_f16.  The weights
-// are the MFMA "A" operand and the activations the "B" operand, so an accumulator register
-// quad holds 4 consecutive n for one m (packs to one 8-byte fp16 store).
-// LDS: rows of 64 halfs (128 B), 16-B chunks XOR-swizzled by (row & 7) -> ds_read_b128 fragment
-// reads and ds_write_b128 staging writes are bank-conflict free.  Global -> register -> LDS
-// staging with the next k-tile's loads in flight under the current tile's MFMAs, two LDS
-// buffers, one barrier per k-tile.  The C tile is staged through LDS so HBM sees whole
-// 16-byte-per-lane row segments (bias / row-broadcast / activation applied in fp32 registers
-// first, the residual added on the way out).
+// Structure (CDNA4, wave64):
+//   * workgroup = NWM x NWN waves, block tile BM x BN x 32, each wave owns (BM/NWM) x (BN/NWN) as
+//     16x16 tiles of v_mfma_f32_16x16x32_f16.  The weights are the MFMA "A" operand and the
+//     activations the "B" operand, so an accumulator register quad holds 4 consecutive n for one m.
+//   * tiles stream global -> LDS with global_load_lds_dwordx4 (LDS-DMA, no staging registers)
+//     into a 4-slot ring: 3 k-tiles in flight per workgroup across ONE raw s_barrier per k-tile,
+//     retired with counted s_waitcnt vmcnt.  Measured: the kernel is bound by the per-CU LDS-DMA
+//     fill rate (~30 GB/s/CU from the Infinity Cache), so the block tile is as large as the
+//     problem allows (256x256 = 128 FLOP per staged byte) and small-M / deep-K problems are split
+//     along K over gridDim.z with a deterministic fp32 slab reduction.
+//   * LDS image: rows of 32 halfs (64 B = 4 chunks of 16 B).  An LDS-DMA instruction writes
+//     64 lanes x 16 B linearly, so the bank swizzle is applied to the per-lane SOURCE chunk
+//     (position p of row r holds global chunk p ^ f(r), f = {0,2,3,1}[(r>>2)&3]) and again on
+//     the fragment read: every ds_read_b128 of a 16x16x32 fragment is bank-conflict free.
+//     Out-of-range rows / taps / k read a 16-byte zero block (LDS-DMA cannot mask a lane).
+//   * workgroup ids are remapped so each XCD owns a contiguous run of tiles, n fastest: the
+//     weight panel and the activation rows a run touches stay in that XCD's L2.
+//   * epilogue: alpha, bias, row-broadcast vector, activation in fp32 registers -> fp16 C tile in
+//     LDS (one wave-row group at a time) -> whole 16-byte row segments to HBM, residual fused.
 #include "common.h"
 #include "../../include/pbe_hip.h"
 
@@ -28,32 +37,53 @@ struct IGemmP {
     float alpha; int act; int bias_row; int vec;
     // conv gather
     int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups;
+    // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
+    int splits; float* ws;
 };
 
-template <int BM, int BN, int MODE>
-__global__ void __launch_bounds__(256) igemm_kernel(const IGemmP p) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int NA = BM * 8 / 256, NW = BN * 8 / 256;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
-    constexpr int CLD = BN + 8;  // C tile leading dim (halfs)
+__device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 0u, 0u};
+
+#define PBE_GLDS16(gsrc, ldst)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),         \
+                                     (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int NWM, int NWN, int MODE>
+__global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    constexpr int NW = NWM * NWN, NT = NW * 64;
+    constexpr int S = 4, D = S - 1;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
+    constexpr int LA = BM / 16 / NW, LW = BN / 16 / NW, LPT = LA + LW;
+    constexpr int CLD = BN + 8;
+    static_assert(LA >= 1 && LW >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "loader pieces must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const long bz = blockIdx.z;
+    const int wm = wave % NWM, wn = wave / NWM;
+    int tile;
+    {   // XCD-aware tile order (bijective for any grid size)
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int tn_i = tile % tiles_n, tm_i = tile / tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const long bz = blockIdx.y;
 
-    const int chunk = tid & 7, rbase = tid >> 3;                 // this thread's 16-B column / first row
-    const int st_off = rbase * 128 + ((chunk ^ (rbase & 7)) << 4);  // + 32*128*i per extra row
+    // ---- loader state: this lane's row inside a 16-row DMA piece and its source chunk ----
+    const int lrow = lane >> 2;
+    const int gch = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);
+    const h16* zsrc = reinterpret_cast<const h16*>(g_pbe_zero16);
 
-    // ---- per-row state of the activation loader ----
-    bool a_ok[NA];
-    const h16* a_row[NA];   // dense: row base (A)      conv: unused
-    const h16* a_row2[NA];  // dense: row base (A2)
-    int cb[NA], cy[NA], cx[NA];
+    bool a_ok[LA];
+    const h16* a_row[LA];
+    const h16* a_row2[LA];
+    int cb[LA], cy[LA], cx[LA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + 32 * i;
+    for (int i = 0; i < LA; ++i) {
+        const int m = m0 + (wave * LA + i) * 16 + lrow;
         a_ok[i] = m < p.M;
         if (MODE == 0) {
             a_row[i] = p.A + bz * p.sA + (long)m * p.lda;
@@ -67,66 +97,58 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IGemmP p) {
             a_row[i] = a_row2[i] = p.A;
         }
     }
-    bool w_ok[NW];
-    const h16* w_row[NW];
+    bool w_ok[LW];
+    const h16* w_row[LW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int n = n0 + rbase + 32 * i;
+    for (int i = 0; i < LW; ++i) {
+        const int n = n0 + (wave * LW + i) * 16 + lrow;
         w_ok[i] = n < p.N;
         w_row[i] = p.W + bz * p.sW + (long)(w_ok[i] ? n : 0) * p.ldw;
     }
-
-    const int nk = (p.K + 63) >> 6;
+    const int nk_all = (p.K + 31) >> 5;
     const int Cin = p.C1 + p.C2;
-    const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int kt0 = 0, nk = nk_all;                        // this workgroup's k-tile range [kt0, nk)
+    if (p.splits > 1) {
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt0 = blockIdx.z * per;
+        nk = min(nk_all, kt0 + per);
+    }
+    int tap = 0, c0 = 0;
+    if (MODE == 1 && kt0 > 0) { tap = (kt0 * 32) / Cin; c0 = kt0 * 32 - tap * Cin; }
 
-    h16x8 ra[NA], rw[NW];
-    int tap = 0, c0 = 0;  // conv: position of the NEXT tile to load
-
-    auto load_tile = [&](int kt) {
-        const int k = kt * 64 + chunk * 8;
+    auto issue = [&](int kt) {
+        unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
+        unsigned char* sw = sa + A_BYTES;
+        const int k = kt * 32 + gch * 8;
         const bool kok = k < p.K;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const bool ok = a_ok[i] && kok;
+            for (int i = 0; i < LA; ++i) {
                 const h16* src = (k < p.K1) ? a_row[i] + k : a_row2[i] + (k - p.K1);
-                src = ok ? src : p.W;
-                h16x8 v = *reinterpret_cast<const h16x8*>(src);
-                ra[i] = ok ? v : zero8;
+                src = (a_ok[i] && kok) ? src : zsrc;
+                PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
             }
         } else {
             const int dy = tap / 3, dx = tap - 3 * dy;
-            const int cc = c0 + chunk * 8;
+            const int cc = c0 + gch * 8;
             const int Hv = p.H << p.ups, Wv = p.Wd << p.ups;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
+            for (int i = 0; i < LA; ++i) {
                 const int iy = cy[i] + dy, ix = cx[i] + dx;
                 const bool ok = a_ok[i] && kok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
                 const long pix = ((long)cb[i] * p.H + (iy >> p.ups)) * p.Wd + (ix >> p.ups);
                 const h16* src = (cc < p.C1) ? p.A + pix * p.C1 + cc : p.A2 + pix * p.C2 + (cc - p.C1);
-                src = ok ? src : p.W;
-                h16x8 v = *reinterpret_cast<const h16x8*>(src);
-                ra[i] = ok ? v : zero8;
+                src = ok ? src : zsrc;
+                PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
             }
-            c0 += 64;
+            c0 += 32;
             if (c0 >= Cin) { c0 = 0; ++tap; }
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const bool ok = w_ok[i] && kok;
-            const h16* src = ok ? w_row[i] + k : p.W;
-            h16x8 v = *reinterpret_cast<const h16x8*>(src);
-            rw[i] = ok ? v : zero8;
+        for (int i = 0; i < LW; ++i) {
+            const h16* src = (w_ok[i] && kok) ? w_row[i] + k : zsrc;
+            PBE_GLDS16(src, sw + (wave * LW + i) * 1024);
         }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sa = smem + buf * BUF;
-        unsigned char* sw = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<h16x8*>(sa + st_off + i * 32 * 128) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<h16x8*>(sw + st_off + i * 32 * 128) = rw[i];
     };
 
     f32x4 acc[TN][TM];
@@ -135,166 +157,264 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IGemmP p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets: row = base + (lane&15), 16-B chunk (ks*4 + lane>>4) ^ (row&7)
     const int fr = lane & 15, fq = lane >> 4;
-    const int a_rd = (wm * WM + fr) * 128, w_rd = (wn * WN + fr) * 128;
-    const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const int rsw = (fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const int a_rd = (wm * WM + fr) * 64 + rsw, w_rd = (wn * WN + fr) * 64 + rsw;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (kt0 + t < nk) issue(kt0 + t);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* sa = smem + cur * BUF;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;                 // tiles issued after tile kt that may stay in flight
+        if (rem >= D - 1) wait_vmcnt<(D - 1) * LPT>();
+        else if (rem == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot (kt-1)%S is free
+        if (kt + D < nk) issue(kt + D);
+        const unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
         const unsigned char* sw = sa + A_BYTES;
+        h16x8 fa[TM], fw[TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int so = ks ? sw1 : sw0;
-            h16x8 fa[TM], fw[TN];
+        for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 64);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 128 + so);
+        for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 64);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 128 + so);
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    if (p.splits > 1) {
+        // raw fp32 partial sums -> slab blockIdx.z; splitk_reduce_kernel applies the epilogue
+        float* slab = p.ws + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + wm * WM + j * 16 + fr;
+                if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = acc[i][j];
+            }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        return;
     }
 
-    // ---- epilogue: registers (alpha, bias, row-broadcast, act) -> fp16 C tile in LDS ----
+    // ---- epilogue: one wave-row group (WM rows of the tile) at a time through LDS ----
     h16* sC = reinterpret_cast<h16*>(smem);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int nl = wn * WN + i * 16 + fq * 4;
-        const int n = n0 + nl;
-        float bn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && !p.bias_row) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bn[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int ml = wm * WM + j * 16 + fr;
-            const int m = m0 + ml;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bn[r];
-            if (p.bias && p.bias_row) {
-                const float bm = (m < p.M) ? p.bias[m] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bm;
-            }
-            if (p.rowvec && m < p.M) {
-                const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] += (float)rv[r];
-            }
-            h16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (h16)apply_act(v[r], p.act);
-            *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
-        }
-    }
-    __syncthreads();
-
-    // ---- C tile -> global, whole 16-byte row segments, residual fused ----
-    constexpr int CPR = BN / 8;
-    constexpr int PER = BM * CPR / 256;
     h16* Cb = p.C + bz * p.sC;
     const h16* Rb = p.resid ? p.resid + bz * p.sR : nullptr;
+    constexpr int CPR = BN / 8;
+    // whole C tile at once when it fits the ring's LDS, else one wave-row group per pass
+    constexpr bool ONE_PASS = (size_t)BM * CLD * 2 <= (size_t)S * STAGE;
+    constexpr int NG = ONE_PASS ? 1 : NWM;            // passes
+    constexpr int GR = ONE_PASS ? BM : WM;            // rows per pass
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        __syncthreads();                              // ring reads (g == 0) / previous group's copy-out done
+        if (ONE_PASS || wm == g) {
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int idx = tid + 256 * it;
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int m = m0 + row, n = n0 + ch * 8;
-        if (m >= p.M || n >= p.N) continue;
-        h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
-        if (p.vec) {
-            if (Rb) {
-                const h16x8 r = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+            for (int i = 0; i < TN; ++i) {
+                const int nl = wn * WN + i * 16 + fq * 4;
+                const int n = n0 + nl;
+                float bn[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && !p.bias_row) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r[e]);
+                    for (int r = 0; r < 4; ++r) bn[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
+                    const int m = m0 + g * GR + ml;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bn[r];
+                    if (p.bias && p.bias_row) {
+                        const float bm = (m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += bm;
+                    }
+                    if (p.rowvec && m < p.M) {
+                        const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) v[r] += (float)rv[r];
+                    }
+                    apply_act4(v, p.act);
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+                    *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
+                }
             }
-            *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n) = v;
-        } else {
+        }
+        __syncthreads();
+        for (int idx = tid; idx < GR * CPR; idx += NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int m = m0 + g * GR + row, n = n0 + ch * 8;
+            if (m >= p.M || n >= p.N) continue;
+            h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
+            if (p.vec) {
+                if (Rb) {
+                    const h16x8 r = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (n + e < p.N) {
-                    float f = (float)v[e];
-                    if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
-                    Cb[(long)m * p.ldc + n + e] = (h16)f;
+                    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r[e]);
+                }
+                *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < p.N) {
+                        float f = (float)v[e];
+                        if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
+                        Cb[(long)m * p.ldc + n + e] = (h16)f;
+                    }
                 }
             }
         }
     }
 }
 
-// ---- host side --------------------------------------------------------------------------------
+// Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue: 4 columns per thread.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N >> 2;
+    if (i >= (long)p.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splits; ++z) a += *reinterpret_cast<const f32x4*>(p.ws + ((long)z * p.M + m) * p.N + n);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.bias_row ? p.bias[m] : p.bias[n + r];
+    }
+    if (p.rowvec) {
+        const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    h16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float f = (float)(h16)apply_act(v[r], p.act);          // same rounding point as the fused epilogue
+        if (p.resid) f += (float)p.resid[(long)m * p.ldr + n + r];
+        o[r] = (h16)f;
+    }
+    *reinterpret_cast<h16x4*>(p.C + (long)m * p.ldc + n) = o;
+}
 
-template <int BM, int BN, int MODE>
-static void launch_igemm(const IGemmP& p, int batch, hipStream_t s) {
-    constexpr size_t main_bytes = 2 * (BM + BN) * 128;
-    constexpr size_t c_bytes = (size_t)BM * (BN + 8) * 2;
-    constexpr size_t lds = main_bytes > c_bytes ? main_bytes : c_bytes;
+// ---- host side --------------------------------------------------------------------------------
+struct Plan { int cfg; int splits; };
+struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
+// eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP)
+static const TileCfg kCfg[] = {
+    {256, 256, 2, 4, 1, 1.00}, {256, 128, 4, 2, 1, 0.80}, {128, 256, 2, 4, 1, 0.80},
+    {128, 128, 2, 2, 2, 0.60}, {128, 64, 2, 2, 2, 0.48}, {64, 128, 2, 2, 2, 0.48}, {64, 64, 2, 2, 2, 0.36}};
+static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
+int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index) forces a tile config; -1 = heuristic
+int g_pbe_allow_splitk = 1;      // pbe_tune(2, 0/1)
+
+static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_bytes, long tiles) {
+    if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) return 1;
+    const int nk = (p.K + 31) >> 5;
+    const long slots = 256L * c.slots_per_cu;
+    if (tiles * 4 > slots * 3 || nk < 16) return 1;          // grid already fills >= 75 % of the chip
+    int s = (int)((slots * 5 / 4 + tiles - 1) / tiles);
+    if (s > nk / 8) s = nk / 8;
+    if (s > 32) s = 32;
+    while (s > 1 && (size_t)s * p.M * p.N * sizeof(float) > ws_bytes) --s;
+    if (s < 2) return 1;
+    const int per = (nk + s - 1) / s;
+    return (nk + per - 1) / per;                      // no empty slice
+}
+
+// Shallow-K problems are dominated by the prologue / epilogue and by HBM traffic, where many small
+// workgroups beat few large ones (measured, tools/bench_kernels.py); deep-K problems by staged
+// bytes per FLOP.  pbe_amd/tuned_mi355x.json overrides this per shape (desc.tile_cfg).
+static const double kEffShallow[] = {0.45, 0.70, 0.70, 0.85, 1.00, 0.95, 0.80};
+
+static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg) {
+    Plan best{3, 1};
+    double best_score = -1.0;
+    const int forced = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : ((want_cfg >= 0 && want_cfg < kNCfg) ? want_cfg : -1);
+    const bool shallow = ((p.K + 31) >> 5) < 48;
+    for (int c = 0; c < kNCfg; ++c) {
+        if (forced >= 0 && c != forced) continue;
+        TileCfg t = kCfg[c];
+        if (shallow) t.eff = kEffShallow[c];
+        const long tm = (p.M + t.bm - 1) / t.bm, tn = (p.N + t.bn - 1) / t.bn;
+        const long tiles = tm * tn * batch;
+        const int sp = splits_for(p, t, batch, ws_bytes, tiles);
+        const double useful = (double)p.M * p.N * batch / ((double)tiles * t.bm * t.bn);
+        const double blocks = (double)tiles * sp, slots = 256.0 * t.slots_per_cu;
+        const double rounds = (double)((long)((blocks + slots - 1) / slots));
+        const double quant = blocks / (rounds * slots);
+        const double split_cost = sp > 1 ? 0.93 : 1.0;        // slab write + reduce launch
+        const double score = t.eff * useful * (0.30 + 0.70 * quant) * split_cost;
+        if (score > best_score) { best_score = score; best = Plan{c, sp}; }
+    }
+    return best;
+}
+
+template <int BM, int BN, int NWM, int NWN, int MODE>
+static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
+    constexpr size_t ring = 4 * (BM + BN) * 64;
+    constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
+    constexpr size_t lds = ring > c_bytes ? ring : c_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), batch);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, s, p);
-}
-
-// Pick the block tile: prefer big tiles, but not when padding waste or a part-filled last
-// wave of workgroups (256 CUs x 2 resident blocks) costs more than the smaller tile's lower
-// MFMA:LDS ratio.
-static void pick_tile(long M, long N, int batch, int* bm, int* bn) {
-    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    static const double eff[4] = {1.0, 0.86, 0.86, 0.72};
-    double best = -1.0;
-    for (int c = 0; c < 4; ++c) {
-        const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
-        const double tiles = (double)tm * tn * batch;
-        const double useful = (double)M * N * batch / (tiles * cand[c][0] * cand[c][1]);
-        const double slots = 512.0;
-        const double rounds = (double)((long)((tiles + slots - 1) / slots));
-        const double quant = tiles / (rounds * slots);
-        const double score = eff[c] * useful * (0.35 + 0.65 * quant);
-        if (score > best) { best = score; *bm = cand[c][0]; *bn = cand[c][1]; }
+    const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
+    dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    if (p.splits > 1) {
+        const long work = (long)p.M * (p.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, p);
     }
 }
 
 template <int MODE>
-static int dispatch_igemm(const IGemmP& p, int batch, hipStream_t s) {
-    int bm = 128, bn = 128;
-    pick_tile(p.M, p.N, batch, &bm, &bn);
-    if (bm == 128 && bn == 128) launch_igemm<128, 128, MODE>(p, batch, s);
-    else if (bm == 128 && bn == 64) launch_igemm<128, 64, MODE>(p, batch, s);
-    else if (bm == 64 && bn == 128) launch_igemm<64, 128, MODE>(p, batch, s);
-    else launch_igemm<64, 64, MODE>(p, batch, s);
-    return 0;
+static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int want_cfg) {
+    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg);
+    p.splits = pl.splits;
+    switch (pl.cfg) {
+        case 0: launch_cfg<256, 256, 2, 4, MODE>(p, batch, s); break;
+        case 1: launch_cfg<256, 128, 4, 2, MODE>(p, batch, s); break;
+        case 2: launch_cfg<128, 256, 2, 4, MODE>(p, batch, s); break;
+        case 3: launch_cfg<128, 128, 2, 2, MODE>(p, batch, s); break;
+        case 4: launch_cfg<128, 64, 2, 2, MODE>(p, batch, s); break;
+        case 5: launch_cfg<64, 128, 2, 2, MODE>(p, batch, s); break;
+        default: launch_cfg<64, 64, 2, 2, MODE>(p, batch, s); break;
+    }
+}
+
+extern "C" int pbe_tune(int32_t key, int32_t value) {
+    if (key == 1) { g_pbe_force_cfg = (value >= 0 && value < kNCfg) ? value : -1; return PBE_OK; }
+    if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
+    return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(d && d->A && d->W && d->C, "pbe_gemm_f16: null operand");
-    PBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "pbe_gemm_f16: bad dims M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
+    PBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1 && d->batch <= 65535, "pbe_gemm_f16: bad dims M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
     PBE_REQUIRE(d->K % 8 == 0, "pbe_gemm_f16: K=%d must be a multiple of 8", d->K);
     PBE_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && al16(d->A) && al16(d->W), "pbe_gemm_f16: A/W must be 16-byte aligned with ld %% 8 == 0");
     PBE_REQUIRE(d->strideA % 8 == 0 && d->strideW % 8 == 0, "pbe_gemm_f16: batch strides of A/W must be multiples of 8");
     const int K1 = d->A2 ? d->K1 : d->K;
     if (d->A2) {
-        PBE_REQUIRE(K1 > 0 && K1 < d->K && K1 % 64 == 0 && d->lda2 % 8 == 0 && al16(d->A2) && d->batch == 1,
-                    "pbe_gemm_f16: split-K source needs K1 %% 64 == 0 (K1=%d), aligned A2, batch 1", K1);
+        PBE_REQUIRE(K1 > 0 && K1 < d->K && K1 % 32 == 0 && d->lda2 % 8 == 0 && al16(d->A2) && d->batch == 1,
+                    "pbe_gemm_f16: split-K source needs K1 %% 32 == 0 (K1=%d), aligned A2, batch 1", K1);
     }
     PBE_REQUIRE(d->lda >= (d->A2 ? K1 : d->K) && d->ldw >= d->K && d->ldc >= d->N, "pbe_gemm_f16: leading dims too small");
     PBE_REQUIRE(!d->rowvec || d->group_rows > 0, "pbe_gemm_f16: rowvec needs group_rows > 0");
@@ -309,9 +429,10 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     p.alpha = d->alpha; p.act = d->act; p.bias_row = d->bias_per_row;
     p.vec = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
+    p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_GEMM, s);
-    dispatch_igemm<0>(p, d->batch, s);
+    dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     pbe_prof_end(PBE_K_GEMM, s, 2.0 * d->M * (double)d->N * d->K * d->batch);
     PBE_LAUNCH_CHECK("pbe_gemm_f16");
     return PBE_OK;
@@ -321,7 +442,7 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(d && d->X && d->Wp && d->Y, "pbe_conv3x3_f16: null operand");
     const int Cin = d->C1 + d->C2;
     PBE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "pbe_conv3x3_f16: bad dims");
-    PBE_REQUIRE(d->C1 > 0 && d->C1 % 64 == 0 && d->C2 >= 0 && d->C2 % 64 == 0, "pbe_conv3x3_f16: C1=%d C2=%d must be multiples of 64 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", d->C1, d->C2);
+    PBE_REQUIRE(d->C1 > 0 && d->C1 % 32 == 0 && d->C2 >= 0 && d->C2 % 32 == 0, "pbe_conv3x3_f16: C1=%d C2=%d must be multiples of 32 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", d->C1, d->C2);
     PBE_REQUIRE((d->C2 == 0) == (d->X2 == nullptr), "pbe_conv3x3_f16: X2 / C2 mismatch");
     PBE_REQUIRE(d->stride == 1 || d->stride == 2, "pbe_conv3x3_f16: stride must be 1 or 2");
     PBE_REQUIRE(d->pad == 0 || d->pad == 1, "pbe_conv3x3_f16: pad must be 0 or 1");
@@ -345,9 +466,10 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     p.vec = (d->Cout % 8 == 0) && (!d->resid || al16(d->resid));
     p.H = d->H; p.Wd = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Ho = Ho; p.Wo = Wo;
     p.cstride = d->stride; p.pad = d->pad; p.ups = d->upsample;
+    p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_CONV3, s);
-    dispatch_igemm<1>(p, 1, s);
+    dispatch_igemm<1>(p, 1, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     pbe_prof_end(PBE_K_CONV3, s, 2.0 * (double)M * d->Cout * 9.0 * Cin);
     PBE_LAUNCH_CHECK("pbe_conv3x3_f16");
     return PBE_OK;

@@ -8,7 +8,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbe_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -19,13 +19,15 @@ class GemmDesc(C.Structure):
                 ("lda", c_i64), ("lda2", c_i64), ("ldw", c_i64), ("ldc", c_i64), ("ldr", c_i64),
                 ("ldv", c_i32), ("group_rows", c_i32),
                 ("strideA", c_i64), ("strideW", c_i64), ("strideC", c_i64), ("strideR", c_i64),
-                ("batch", c_i32), ("alpha", c_f32), ("act", c_i32), ("bias_per_row", c_i32)]
+                ("batch", c_i32), ("alpha", c_f32), ("act", c_i32), ("bias_per_row", c_i32),
+                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32)]
 
 
 class Conv3x3Desc(C.Structure):
     _fields_ = [("X", c_vp), ("X2", c_vp), ("Wp", c_vp), ("Y", c_vp), ("bias", c_vp), ("rowvec", c_vp), ("resid", c_vp),
                 ("B", c_i32), ("H", c_i32), ("W", c_i32), ("C1", c_i32), ("C2", c_i32), ("Cout", c_i32),
-                ("stride", c_i32), ("pad", c_i32), ("upsample", c_i32), ("ldv", c_i32), ("act", c_i32)]
+                ("stride", c_i32), ("pad", c_i32), ("upsample", c_i32), ("ldv", c_i32), ("act", c_i32),
+                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32)]
 
 
 class AttnDesc(C.Structure):
@@ -58,6 +60,7 @@ SYMBOLS = {
     "pbe_clip_patchify_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_bcast_row_f16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "pbe_image_post_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "pbe_tune": (c_i32, [c_i32, c_i32]),
     "pbe_prof_enable": (c_i32, [c_i32]),
     "pbe_prof_reset": (c_i32, []),
     "pbe_prof_collect": (c_i32, [C.POINTER(C.c_double), c_i32]),

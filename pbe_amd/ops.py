@@ -41,6 +41,37 @@ def _f(t, what):
     return _req(t, torch.float32, what)
 
 
+SPLITK_WS_BYTES = 64 << 20
+
+# ---- per-shape tile choice measured on MI355X (tools/autotune.py writes the table) -------------
+import json as _json
+import os as _os
+
+_TUNED_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned_mi355x.json")
+try:
+    with open(_TUNED_PATH) as _tuned_file:
+        _TUNED = _json.load(_tuned_file)
+except (OSError, ValueError):
+    _TUNED = {}
+_RECORD = None            # set to a dict by tools/autotune.py to collect the shapes a workload uses
+
+
+def _tile_cfg(key: str) -> int:
+    if _RECORD is not None:
+        _RECORD[key] = _RECORD.get(key, 0) + 1
+    return int(_TUNED.get(key, -1))
+
+
+def _splitk_ws(device):
+    """Per-device scratch for split-K partial sums (fp32 slabs); ops on one stream run in order, so one buffer is enough."""
+    key = (device.index, "splitk")
+    ws = _ws.get(key)
+    if ws is None:
+        ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+        _ws[key] = ws
+    return ws
+
+
 def _rows(t: torch.Tensor, what: str) -> Tuple[int, int, int]:
     """(rows, cols, ld) of a 2-D view whose last dim is contiguous."""
     if t.dim() != 2 or t.stride(1) != 1:
@@ -98,7 +129,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if group_rows <= 0:
             raise _l.PbeError("gemm: rowvec needs group_rows")
     d = _l.GemmDesc(_p(a), _p(a2), _p(w), _p(_h(out, "gemm out")), _p(bias), _p(rowvec), _p(resid), M, N, K, K1, lda, lda2, ldw, ldc, ldr,
-                    ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0)
+                    ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0,
+                    _splitk_ws(a.device).data_ptr(), SPLITK_WS_BYTES, _tile_cfg(f"g:{M}:{N}:{K}:{batch}"))
     _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
     return out
 
@@ -141,7 +173,8 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
     if bias is not None:
         _f(bias, "conv3x3 bias")
     d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
-                       1 if upsample else 0, ldv, act)
+                       1 if upsample else 0, ldv, act, _splitk_ws(x.device).data_ptr(), SPLITK_WS_BYTES,
+                       _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"))
     _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
     return y
 
@@ -344,6 +377,10 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+def tune(key: int, value: int) -> None:
+    _l.check(_l.load().pbe_tune(key, value), "pbe_tune")
 
 
 # ---- profiling --------------------------------------------------------------------------------

@@ -75,6 +75,24 @@ def test_gemm_epilogue(dev, act):
     _close(got, ref, what=f"gemm epilogue act={act}")
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 5120), (256, 640, 2048), (130, 320, 4096)])
+def test_gemm_split_k_reduction(dev, M, N, K):
+    """Few tiles + deep K -> the kernel splits K across workgroups and reduces fp32 slabs; epilogue must match."""
+    from pbe_amd import ops
+    g = _g(M + K)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    bias = torch.randn(N, generator=g)
+    rv = torch.randn((M + 63) // 64, N, generator=g).half()
+    res = torch.randn(M, N, generator=g).half()
+    pre = a.float() @ w.float().t() + bias + rv.float().repeat_interleave(64, 0)[:M]
+    ref = F.silu(pre).half().float() + res.float()
+    got = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), rowvec=rv.to(dev), group_rows=64, resid=res.to(dev), act=1)
+    _close(got, ref, what=f"gemm split-K {M}x{N}x{K}")
+    got2 = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), rowvec=rv.to(dev), group_rows=64, resid=res.to(dev), act=1)
+    assert torch.equal(got, got2), "split-K reduction must be deterministic"
+
+
 def test_gemm_split_k_sources_and_bias_per_row(dev):
     from pbe_amd import ops
     g = _g(5)
@@ -119,7 +137,7 @@ def _conv_ref(x, w, b, stride, pad, ups, x2=None):
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride,pad,ups", [
     (2, 16, 16, 64, 128, 1, 1, False), (1, 12, 20, 128, 64, 1, 1, False), (2, 16, 16, 64, 64, 2, 1, False),
     (2, 16, 16, 64, 64, 2, 0, False), (2, 8, 8, 128, 128, 1, 1, True), (3, 9, 7, 192, 320, 1, 1, False),
-    (1, 64, 64, 320, 320, 1, 1, False)])
+    (1, 64, 64, 320, 320, 1, 1, False), (8, 8, 8, 1280, 1280, 1, 1, False), (4, 16, 16, 640, 640, 2, 1, False), (2, 8, 8, 640, 320, 1, 1, True)])
 def test_conv3x3(dev, B, H, W, Ci, Co, stride, pad, ups):
     from pbe_amd import ops
     g = _g(H * 31 + Ci)
