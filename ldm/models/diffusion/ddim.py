@@ -35,7 +35,7 @@ class DDIMSampler(PLMSSampler):
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, **kwargs):
         device = self.model.betas.device
-        if device.type != "cuda":
+        if self.require_gpu and device.type != "cuda":
             raise PbeError("DDIMSampler: the model must live on an MI355X; there is no CPU path")
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
