@@ -192,3 +192,22 @@ def test_instantiate_from_config_and_tuned_table():
         instantiate_from_config({"params": {}})
     table = json.load(open(os.path.join(ROOT, "pbe_amd", "tuned_mi355x.json")))
     assert table and all(0 <= int(v) <= 6 for v in table.values())
+
+
+def test_preprocessing_of_bundled_example(golden_dir):
+    """scripts/inference.py:306-318 on the reference's own examples/example_1 triple (data files copied
+    into tests/golden/examples/): the product's loader against the oracle's statement of the formulas."""
+    from PIL import Image
+    from pbe_amd import preprocess
+    d = os.path.join(golden_dir, "examples")
+    t = preprocess.load_triple(os.path.join(d, "image_example_1.png"), os.path.join(d, "mask_example_1.png"), os.path.join(d, "reference_example_1.jpg"))
+    img = np.asarray(Image.open(os.path.join(d, "image_example_1.png")).convert("RGB"))
+    msk = np.asarray(Image.open(os.path.join(d, "mask_example_1.png")).convert("L"))
+    ref = np.asarray(Image.open(os.path.join(d, "reference_example_1.jpg")).convert("RGB").resize((224, 224)))
+    oi, oinp, om, oref = O.preprocess_triple(img, msk, ref)
+    assert t["image"].shape == (1, 3, 512, 512) and t["ref"].shape == (1, 3, 224, 224)
+    assert torch.equal(t["image"], oi) and torch.equal(t["mask"], om) and torch.equal(t["inpaint"], oinp)
+    assert torch.allclose(t["ref"], oref, atol=1e-6)
+    assert set(torch.unique(t["mask"]).tolist()) == {0.0, 1.0} and 0.05 < 1 - t["mask"].mean().item() < 0.6
+    from pbe_amd.pipeline import resize_mask
+    assert torch.equal(resize_mask(t["mask"], (64, 64)), O.resize_mask(t["mask"], (64, 64), True))

@@ -217,3 +217,21 @@ def test_full_clip(dev, gold, full):
     with torch.no_grad():
         pooled = full.cond_stage_model.transformer(pixel_values=inp["ref"].to(dev)).pooler_output
     check("v1 CLIP ViT-L/14 pooled", pooled, gold["full"]["clip_pooled"])
+
+
+def test_inference_cli_on_bundled_example(dev, golden_dir, tmp_path):
+    """scripts/inference.py counterpart end to end on examples/example_1 (BASELINE config #1 inputs; seed 321,
+    scale 5 as in the reference's test.sh) with name-seeded weights, 4 PLMS steps: files written, image finite."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pbe_inference_cli", os.path.join(root, "scripts", "inference.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    d = os.path.join(golden_dir, "examples")
+    out = cli.main(["--plms", "--outdir", str(tmp_path), "--config", os.path.join(root, "configs", "v1.yaml"), "--ddim_steps", "4",
+                    "--image_path", os.path.join(d, "image_example_1.png"), "--mask_path", os.path.join(d, "mask_example_1.png"),
+                    "--reference_path", os.path.join(d, "reference_example_1.jpg"), "--seed", "321", "--scale", "5", "--fixed_code"])
+    assert out.shape == (1, 3, 512, 512) and torch.isfinite(out).all() and 0 <= out.min() and out.max() <= 1
+    for sub, name in (("results", "image_example_1_321.png"), ("grid", "grid-image_example_1_321.png"), ("source", "image_example_1_321_mask.png"),
+                      ("source", "image_example_1_321_GT.png"), ("source", "image_example_1_321_inpaint.png"), ("source", "image_example_1_321_ref.png")):
+        assert os.path.getsize(os.path.join(str(tmp_path), sub, name)) > 0
