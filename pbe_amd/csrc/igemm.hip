@@ -115,6 +115,10 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     }
     int tap = 0, c0 = 0;
     if (MODE == 1 && kt0 > 0) { tap = (kt0 * 32) / Cin; c0 = kt0 * 32 - tap * Cin; }
+    const h16* a_src[LA];
+    bool a_val[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) { a_src[i] = zsrc; a_val[i] = false; }
 
     auto issue = [&](int kt) {
         unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
@@ -129,17 +133,23 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
             }
         } else {
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            const int cc = c0 + gch * 8;
-            const int Hv = p.H << p.ups, Wv = p.Wd << p.ups;
+            // the gather address is recomputed only when the tap (or the concat source) changes;
+            // inside a tap consecutive k-tiles are +32 channels of the same pixel
+            if (c0 == 0 || c0 == p.C1 || kt == kt0) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                const int Hv = p.H << p.ups, Wv = p.Wd << p.ups;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    const int iy = cy[i] + dy, ix = cx[i] + dx;
+                    a_val[i] = a_ok[i] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                    const long pix = ((long)cb[i] * p.H + (iy >> p.ups)) * p.Wd + (ix >> p.ups);
+                    a_src[i] = (c0 < p.C1) ? p.A + pix * p.C1 + c0 + gch * 8 : p.A2 + pix * p.C2 + (c0 - p.C1) + gch * 8;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                const int iy = cy[i] + dy, ix = cx[i] + dx;
-                const bool ok = a_ok[i] && kok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                const long pix = ((long)cb[i] * p.H + (iy >> p.ups)) * p.Wd + (ix >> p.ups);
-                const h16* src = (cc < p.C1) ? p.A + pix * p.C1 + cc : p.A2 + pix * p.C2 + (cc - p.C1);
-                src = ok ? src : zsrc;
-                PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
+                PBE_GLDS16(a_val[i] ? a_src[i] : zsrc, sa + (wave * LA + i) * 1024);
+                a_src[i] += 32;
             }
             c0 += 32;
             if (c0 >= Cin) { c0 = 0; ++tap; }
@@ -172,7 +182,6 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot (kt-1)%S is free
-        if (kt + D < nk) issue(kt + D);
         const unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
         const unsigned char* sw = sa + A_BYTES;
         h16x8 fa[TM], fw[TN];
@@ -180,11 +189,16 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 64);
 #pragma unroll
         for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);           // fragment reads go out first; the DMA address math runs in their shadow
+        if (kt + D < nk) issue(kt + D);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
