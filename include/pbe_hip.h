@@ -41,6 +41,7 @@ extern "C" {
 #define PBE_ACT_SILU 1
 #define PBE_ACT_GELU_ERF 2
 #define PBE_ACT_QUICK_GELU 3
+#define PBE_ACT_GEGLU 4 /* GEMM only: W rows interleaved (x_j, gate_j); C[m, j] = x_j * gelu_erf(gate_j), width N/2 (attention.py:43-45) */
 
 typedef void* pbe_stream_t; /* hipStream_t */
 

@@ -53,13 +53,16 @@ class GEGLU(HipModule):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def _pack(self):
-        return SimpleNamespace(w=ops.pack_linear(self.proj.weight), b=f32(self.proj.bias))
+        wi, bi = ops.pack_geglu(self.proj.weight.detach(), self.proj.bias.detach())
+        return SimpleNamespace(w=wi, b=bi)          # (value, gate) rows interleaved: gating fused in the GEMM epilogue
+
+    def run(self, x2d):
+        p = self.pk()
+        return ops.gemm(x2d, p.w, p.b, act=ops.ACT_GEGLU)
 
     def forward(self, x):
-        p = self.pk()
         x = _tokens(x)
-        h = ops.gemm(x.view(-1, x.shape[-1]), p.w, p.b)
-        return ops.geglu(h).view(*x.shape[:-1], -1)
+        return self.run(x.view(-1, x.shape[-1])).view(*x.shape[:-1], -1)
 
 
 class FeedForward(HipModule):
@@ -76,10 +79,8 @@ class FeedForward(HipModule):
 
     def run(self, x2d, resid=None):
         """x2d [M, C] fp16 -> Linear(GEGLU(x)) (+ resid)."""
-        g = self.net[0].pk()
         p = self.pk()
-        h = ops.geglu(ops.gemm(x2d, g.w, g.b))
-        return ops.gemm(h, p.w2, p.b2, resid=resid)
+        return ops.gemm(self.net[0].run(x2d), p.w2, p.b2, resid=resid)
 
     def forward(self, x):
         x = _tokens(x)

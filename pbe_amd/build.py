@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, "libpbe_hip.so")
 SOURCES = ["runtime.hip", "igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
+# per-file extras: keep MFMA results in VGPRs where the VALU consumes them right away (attention softmax),
+# saving ~100 v_accvgpr_read/write per K/V tile
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -36,9 +39,9 @@ def _stale(target: str, deps) -> bool:
 
 def _compile(src: str, extra) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pbe_hip.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pbe_hip.h"), os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

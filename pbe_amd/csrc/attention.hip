@@ -23,19 +23,21 @@ struct AttnP {
     float scale_log2e;
 };
 
-template <int DP>
+template <int DP, int KT>
 __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int NDS = DP / 16;          // k-steps of the QK^T product
     constexpr int NDT = DV / 32;          // 32-wide d tiles of the output
     constexpr int DC = DP / 8;            // 16-B chunks per K row
     constexpr int KSTR = (DC | 1) * 16;   // K tile row stride, bytes (odd number of 16-B units)
-    constexpr int VSTR = 136;             // V^T tile row stride, bytes
-    constexpr int K_BYTES = 64 * KSTR;
+    constexpr int NH = KT / 64;           // 64-key halves per staged tile (one barrier per KT keys)
+    constexpr int VSTR = KT * 2 + 8;      // V^T tile row stride, bytes (8 mod 128: conflict-free ds_read_b64)
+    constexpr int K_BYTES = KT * KSTR;
     constexpr int V_BYTES = DV * VSTR;
     constexpr int BUF = (K_BYTES + V_BYTES + 15) / 16 * 16;
-    constexpr int KCH = 64 * DC, NKL = (KCH + 255) / 256;
-    constexpr int VCH = DV * 8, NVL = (VCH + 255) / 256;
+    constexpr int KCH = KT * DC, NKL = (KCH + 255) / 256;
+    constexpr int VPR = KT / 8;           // 16-B chunks per V^T row
+    constexpr int VCH = DV * VPR, NVL = (VCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,6 +46,11 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const int D = p.D;
     const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const h16x8 one8 = {1, 1, 1, 1, 1, 1, 1, 1};
+    // When the d-tile padding leaves a free row (DV > DP), row DV-1 of the V^T tile is all ones: the PV
+    // MFMA then accumulates the softmax denominator sum_k P[k] in O^T[DV-1] for free (same rescaling as O),
+    // and the 32 VALU adds per tile disappear.  Otherwise the denominator is summed on the VALU.
+    constexpr bool ONES = DV > DP;
 
     const h16* Qb = p.Q + (long)b * p.q_bs + (long)h * D;
     const h16* Kb = p.K + (long)b * p.k_bs + (long)h * D;
@@ -62,7 +69,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
 
     h16x8 rk[NKL], rv[NVL];
     auto load_tile = [&](int t) {
-        const int kv0 = t * 64;
+        const int kv0 = t * KT;
 #pragma unroll
         for (int i = 0; i < NKL; ++i) {
             const int idx = tid + 256 * i;
@@ -75,13 +82,14 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
 #pragma unroll
         for (int i = 0; i < NVL; ++i) {
             const int idx = tid + 256 * i;
-            const int row = idx >> 3, ch = idx & 7;
+            const int row = idx / VPR, ch = idx - row * VPR;
             const int key0 = kv0 + ch * 8;
             const bool ok = idx < VCH && row < D && key0 < p.Nk;
             const h16* src = ok ? Vb + (long)row * p.vt_rs + key0 : p.VT;
             h16x8 v = *reinterpret_cast<const h16x8*>(src);
             v = ok ? v : zero8;
-            if (ok && key0 + 8 > p.Nk) {
+            if (ONES && idx < VCH && row == DV - 1 && key0 < p.Nk) v = one8;      // denominator row (see below)
+            if (key0 < p.Nk && key0 + 8 > p.Nk) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (key0 + e >= p.Nk) v[e] = (h16)0.f;
@@ -101,7 +109,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
 #pragma unroll
         for (int i = 0; i < NVL; ++i) {
             const int idx = tid + 256 * i;
-            const int row = idx >> 3, ch = idx & 7;
+            const int row = idx / VPR, ch = idx - row * VPR;
             if (idx < VCH) {
                 h16x4 lo = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
                 h16x4 hi = {rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nt = (p.Nk + 63) >> 6;
+    const int nt = (p.Nk + KT - 1) / KT;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -129,48 +137,58 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         const unsigned char* sk = smem + cur * BUF;
         const unsigned char* sv = sk + K_BYTES;
 
+#pragma unroll 1
+        for (int hk = 0; hk < NH; ++hk) {
+        if (t * KT + hk * 64 >= p.Nk) break;           // staged tile padded past the last key
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
-            const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+            const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + (hk * 64 + l31) * KSTR + (ds * 2 + h5) * 16);
+            const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (hk * 64 + 32 + l31) * KSTR + (ds * 2 + h5) * 16);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ds], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ds], s1, 0, 0, 0);
         }
         // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32) ----
-        const int kv0 = t * 64;
-        const bool tail = kv0 + 64 > p.Nk;
-        float mx = -INFINITY;
+        // VALU budget matters here (d = 40: 14 MFMAs per tile vs ~200 VALU ops): the max runs on RAW scores,
+        // the scale is folded into the exp2 argument (one FMA), O is rescaled only when some lane's max grew.
+        const int kv0 = t * KT + hk * 64;
+        if (kv0 + 64 > p.Nk) {                          // tail tile only (wave-uniform branch, selects inside)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = s0[r] * p.scale_log2e, c = s1[r] * p.scale_log2e;
-            if (tail) {
+            for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-                if (key >= p.Nk) a = -INFINITY;
-                if (key + 32 >= p.Nk) c = -INFINITY;
+                s0[r] = (key >= p.Nk) ? -INFINITY : s0[r];
+                s1[r] = (key + 32 >= p.Nk) ? -INFINITY : s1[r];
             }
-            s0[r] = a; s1[r] = c;
-            mx = fmaxf(mx, fmaxf(a, c));
         }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+        const float m_new = fmaxf(m_run, mx * p.scale_log2e);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {      // some query's running max grew in this wave
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float neg_m = -m_run;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            psum += s0[r] + s1[r];
+            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
         }
-        l_run = l_run * alpha + psum;
+        if (!ONES) {
+            float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NDT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            for (int r = 0; r < 16; ++r) psum += s0[r] + s1[r];
+            l_run += psum;
+        }
 
         // ---- P^T fragments straight from the accumulator registers (permuted k order) ----
         h16x8 pf[4];
@@ -184,7 +202,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + 8 * h5;
+            const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + hk * 128 + 8 * h5;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {   // ks = sub*2 + s : keys sub*32 + 16 s + {4h..4h+3, 8+4h..}
                 const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow + ks * 32);
@@ -193,12 +211,20 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
             }
         }
+        }
         if (t + 1 < nt) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- normalise and store O[q, h*D + d] ----
-    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    float l;
+    if (ONES) {                                           // O^T row DV-1 lives in register 15 of the upper half-wave
+        const float mine = o[NDT - 1][15];
+        const float other = __shfl_xor(mine, 32, 64);
+        l = h5 ? mine : other;
+    } else {
+        l = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l;
     if (q < p.Nq) {
         h16* Ob = p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D;
@@ -217,19 +243,19 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     }
 }
 
-template <int DP>
+template <int DP, int KT>
 static void launch_attn(const AttnP& p, hipStream_t s) {
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int KSTR = ((DP / 8) | 1) * 16;
-    constexpr int BUF = (64 * KSTR + DV * 136 + 15) / 16 * 16;
+    constexpr int BUF = (KT * KSTR + DV * (KT * 2 + 8) + 15) / 16 * 16;
     constexpr size_t lds = 2 * BUF;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
-    hipLaunchKernelGGL((attn_kernel<DP>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_kernel<DP, KT>), grid, dim3(256), lds, s, p);
 }
 
 extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
@@ -252,13 +278,15 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_ATTN, s);
     const int D = d->D;
-    if (D <= 16) launch_attn<16>(p, s);
-    else if (D <= 32) launch_attn<32>(p, s);
-    else if (D <= 48) launch_attn<48>(p, s);
-    else if (D <= 64) launch_attn<64>(p, s);
-    else if (D <= 80) launch_attn<80>(p, s);
-    else if (D <= 128) launch_attn<128>(p, s);
-    else launch_attn<160>(p, s);
+    // long sequences stage 128 keys per barrier (halves the exposed load latency); short ones 64
+    const bool big = false;   // measured: 128-key tiles halve the resident workgroups (LDS) and run 27 % slower at N=4096, d=40
+    if (D <= 16) launch_attn<16, 64>(p, s);
+    else if (D <= 32) launch_attn<32, 64>(p, s);
+    else if (D <= 48) { if (big) launch_attn<48, 128>(p, s); else launch_attn<48, 64>(p, s); }
+    else if (D <= 64) { if (big) launch_attn<64, 128>(p, s); else launch_attn<64, 64>(p, s); }
+    else if (D <= 80) { if (big) launch_attn<80, 128>(p, s); else launch_attn<80, 64>(p, s); }
+    else if (D <= 128) launch_attn<128, 64>(p, s);
+    else launch_attn<160, 64>(p, s);
     pbe_prof_end(PBE_K_ATTN, s, 4.0 * d->B * d->H * (double)d->Nq * d->Nk * d->D);
     PBE_LAUNCH_CHECK("pbe_attention_f16");
     return PBE_OK;

@@ -257,19 +257,26 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                         for (int r = 0; r < 4; ++r)
                             if (n + r < p.N) v[r] += (float)rv[r];
                     }
-                    apply_act4(v, p.act);
-                    h16x4 o;
+                    if (p.act == PBE_ACT_GEGLU) {            // columns interleaved (x_j, gate_j): out_j = x_j * gelu(gate_j)
+                        h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
+                        *reinterpret_cast<h16x2*>(sC + ml * CLD + (nl >> 1)) = o2;
+                    } else {
+                        apply_act4(v, p.act);
+                        h16x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
-                    *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
+                        for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+                        *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
+                    }
                 }
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < GR * CPR; idx += NT) {
-            const int row = idx / CPR, ch = idx - row * CPR;
-            const int m = m0 + g * GR + row, n = n0 + ch * 8;
-            if (m >= p.M || n >= p.N) continue;
+        const bool gg = p.act == PBE_ACT_GEGLU;             // GEGLU halves the output width
+        const int cpr = gg ? CPR / 2 : CPR, Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
+        for (int idx = tid; idx < GR * cpr; idx += NT) {
+            const int row = idx / cpr, ch = idx - row * cpr;
+            const int m = m0 + g * GR + row, n = nb + ch * 8;
+            if (m >= p.M || n >= Nout) continue;
             h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
             if (p.vec) {
                 if (Rb) {
@@ -281,7 +288,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if (n + e < p.N) {
+                    if (n + e < Nout) {
                         float f = (float)v[e];
                         if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
                         Cb[(long)m * p.ldc + n + e] = (h16)f;
@@ -311,6 +318,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
         const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    if (p.act == PBE_ACT_GEGLU) {
+        h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
+        *reinterpret_cast<h16x2*>(p.C + (long)m * p.ldc + (n >> 1)) = o2;
+        return;
     }
     h16x4 o;
 #pragma unroll
@@ -430,8 +442,11 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
         PBE_REQUIRE(K1 > 0 && K1 < d->K && K1 % 32 == 0 && d->lda2 % 8 == 0 && al16(d->A2) && d->batch == 1,
                     "pbe_gemm_f16: split-K source needs K1 %% 32 == 0 (K1=%d), aligned A2, batch 1", K1);
     }
-    PBE_REQUIRE(d->lda >= (d->A2 ? K1 : d->K) && d->ldw >= d->K && d->ldc >= d->N, "pbe_gemm_f16: leading dims too small");
+    PBE_REQUIRE(d->lda >= (d->A2 ? K1 : d->K) && d->ldw >= d->K, "pbe_gemm_f16: leading dims too small");
     PBE_REQUIRE(!d->rowvec || d->group_rows > 0, "pbe_gemm_f16: rowvec needs group_rows > 0");
+    const bool geglu = d->act == PBE_ACT_GEGLU;
+    const int Nout = geglu ? d->N / 2 : d->N;
+    PBE_REQUIRE(!geglu || (d->N % 16 == 0 && !d->resid && !d->rowvec && !d->bias_per_row), "pbe_gemm_f16: GEGLU epilogue needs N %% 16 == 0 and no resid/rowvec");
     IGemmP p;
     memset(&p, 0, sizeof(p));
     p.A = (const h16*)d->A; p.A2 = (const h16*)d->A2; p.W = (const h16*)d->W; p.C = (h16*)d->C;
@@ -441,7 +456,8 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     p.ldv = d->ldv; p.group_rows = d->group_rows > 0 ? d->group_rows : 1;
     p.sA = d->strideA; p.sW = d->strideW; p.sC = d->strideC; p.sR = d->strideR;
     p.alpha = d->alpha; p.act = d->act; p.bias_row = d->bias_per_row;
-    p.vec = (d->N % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
+    PBE_REQUIRE(d->ldc >= Nout, "pbe_gemm_f16: ldc too small");
+    p.vec = (Nout % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
     p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;

@@ -35,7 +35,17 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const h16* X, const h16* 
             float a[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
-            for (int r = r0 + ty; r < r1; r += TY) {
+            int r = r0 + ty;
+            for (; r + 3 * TY < r1; r += 4 * TY) {      // 4 independent 16-byte loads in flight per lane
+                h16x8 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, (long)b * HW + r + u * TY, v));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)x[u][e]; a[e] += f; q[e] += f * f; }
+            }
+            for (; r < r1; r += TY) {
                 const h16x8 x = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, (long)b * HW + r, v));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; a[e] += f; q[e] += f * f; }
@@ -109,7 +119,24 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const h16* X, const h16* 
             const float a = s_rstd[g] * gamma[c];
             sc[e] = a; sh[e] = beta[c] - s_mean[g] * a;
         }
-        for (int r = r0 + ty; r < r1; r += TY) {
+        int r = r0 + ty;
+        for (; r + 3 * TY < r1; r += 4 * TY) {
+            h16x8 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, (long)b * HW + r + u * TY, v));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)x[u][e] * sc[e] + sh[e];
+                    if (silu) f = silu_f(f);
+                    y[e] = (h16)f;
+                }
+                *reinterpret_cast<h16x8*>(Y + ((long)b * HW + r + u * TY) * C + v * 8) = y;
+            }
+        }
+        for (; r < r1; r += TY) {
             const long row = (long)b * HW + r;
             const h16x8 x = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, row, v));
             h16x8 y;
@@ -124,11 +151,67 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const h16* X, const h16* 
     }
 }
 
+// Small feature maps (the 16x16 / 8x8 U-Net levels): one workgroup per (sample, group) keeps its
+// HW x (C/groups) slice in registers, so statistics and normalisation are ONE launch and one read.
+// Needs C/groups % 8 == 0 and HW <= GN_SMALL_ROWS * (256 / (C/groups/8)).
+#define GN_SMALL_ROWS 12
+__global__ void __launch_bounds__(256) gn_small_kernel(const h16* X, const h16* X2, const float* gamma, const float* beta, h16* Y,
+                                                        int HW, int C1, int C2, int groups, float eps, int silu) {
+    __shared__ float s_a[4], s_q[4];
+    const int C = C1 + C2, cg = C / groups, TX = cg >> 3, TY = 256 / TX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tid % TX, ty = tid / TX;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int v = (g * cg >> 3) + tx;
+    const bool act = ty < TY;
+    h16x8 x[GN_SMALL_ROWS];
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int u = 0; u < GN_SMALL_ROWS; ++u) {
+        const int r = ty + u * TY;
+        if (act && r < HW) {
+            x[u] = *reinterpret_cast<const h16x8*>(gn_src(X, X2, C1, C2, (long)b * HW + r, v));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)x[u][e]; a += f; q += f * f; }
+        }
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if (lane == 0) { s_a[wave] = a; s_q[wave] = q; }
+    __syncthreads();
+    const double n = (double)HW * cg;
+    const double mean = ((double)s_a[0] + s_a[1] + s_a[2] + s_a[3]) / n;
+    double var = ((double)s_q[0] + s_q[1] + s_q[2] + s_q[3]) / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (!act) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        sc[e] = rstd * gamma[c];
+        sh[e] = beta[c] - mu * sc[e];
+    }
+#pragma unroll
+    for (int u = 0; u < GN_SMALL_ROWS; ++u) {
+        const int r = ty + u * TY;
+        if (r < HW) {
+            h16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)x[u][e] * sc[e] + sh[e];
+                if (silu) f = silu_f(f);
+                y[e] = (h16)f;
+            }
+            *reinterpret_cast<h16x8*>(Y + ((long)b * HW + r) * C + v * 8) = y;
+        }
+    }
+}
+
 static void gn_geometry(int HW, int C, int* nchunks, int* rpb, int* TX, int* TY) {
     const int C8 = C / 8;
     *TX = C8 < 256 ? C8 : 256;
     *TY = 256 / *TX;
-    int rows = *TY * 8;                       // >= 8 rows per thread-row per block
+    int rows = *TY * 16;                      // 16 rows per thread: four 4-deep load batches
     if (rows < 32) rows = 32;
     int n = (HW + rows - 1) / rows;
     if (n > GN_MAX_CHUNKS) { n = GN_MAX_CHUNKS; rows = (HW + n - 1) / n; n = (HW + rows - 1) / rows; }
@@ -151,9 +234,18 @@ extern "C" int pbe_groupnorm_f16(const void* X, const void* X2, const float* gam
     PBE_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "pbe_groupnorm_f16: groups=%d must divide C=%d (<= 64)", groups, C);
     PBE_REQUIRE(B <= 65535, "pbe_groupnorm_f16: batch too large");
     PBE_REQUIRE(workspace_bytes >= pbe_groupnorm_workspace_bytes(B, HW), "pbe_groupnorm_f16: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int cg = C / groups;
+    if (cg % 8 == 0 && cg / 8 <= 64 && HW <= GN_SMALL_ROWS * (256 / (cg / 8))) {
+        pbe_prof_begin(PBE_K_GNORM, s);
+        hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, gamma, beta, (h16*)Y, HW, C1, C2,
+                           groups, eps, silu);
+        pbe_prof_end(PBE_K_GNORM, s, 4.0 * B * (double)HW * C);
+        PBE_LAUNCH_CHECK("pbe_groupnorm_f16");
+        return PBE_OK;
+    }
     int nchunks, rpb, TX, TY;
     gn_geometry(HW, C, &nchunks, &rpb, &TX, &TY);
-    hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_GNORM, s);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (float*)workspace, HW, C1, C2,
                        groups, rpb, TX, TY);

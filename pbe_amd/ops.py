@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _l
 
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 _ws = {}
 
 
@@ -107,7 +107,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         M, K, lda = _rows(a, "gemm a")
         N, Kw, ldw = _rows(w, "gemm w")
         if out is None:
-            out = torch.empty((M, N), dtype=torch.float16, device=a.device)
+            out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), dtype=torch.float16, device=a.device)
         ldc = _rows(out, "gemm out")[2]
         ldr = 0
         if resid is not None:
@@ -377,6 +377,15 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU projection [2F, K] (rows 0..F-1 = value, F..2F-1 = gate, attention.py:41-45) -> rows interleaved
+    (x_0, g_0, x_1, g_1, ...) so the GEMM epilogue sees each (value, gate) pair in one accumulator quad."""
+    F = w.shape[0] // 2
+    wi = torch.stack([w[:F], w[F:]], 1).reshape(2 * F, -1)
+    bi = torch.stack([b[:F], b[F:]], 1).reshape(2 * F)
+    return wi.to(torch.float16).contiguous(), bi.detach().float().contiguous()
 
 
 def tune(key: int, value: int) -> None:

@@ -334,3 +334,35 @@ def test_errors_are_loud(dev):
         ops.gemm(torch.zeros(8, 12, dtype=torch.float16, device=dev), torch.zeros(8, 12, dtype=torch.float16, device=dev))  # K % 8
     with pytest.raises(PbeError):
         ops.conv3x3(torch.zeros(1, 4, 4, 9, dtype=torch.float16, device=dev), torch.zeros(8, 81, dtype=torch.float16, device=dev), None)
+
+
+@pytest.mark.parametrize("M,F,K", [(300, 256, 64), (4096, 1280, 320), (64, 5120, 1280)])
+def test_gemm_fused_geglu(dev, M, F, K):
+    """attention.py:41-45: x, gate = proj(x).chunk(2); x * gelu(gate) — fused in the GEMM epilogue (interleaved rows)."""
+    from pbe_amd import ops
+    g = _g(M + F)
+    a = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(2 * F, K, generator=g) / math.sqrt(K)).half()
+    b = torch.randn(2 * F, generator=g) * 0.1
+    h = a.float() @ w.float().t() + b
+    ref = h[:, :F] * F_gelu(h[:, F:])
+    wi, bi = ops.pack_geglu(w.float().to(dev), b.to(dev))
+    got = ops.gemm(a.to(dev), wi, bi, act=ops.ACT_GEGLU)
+    assert got.shape == (M, F)
+    _close(got, ref, what=f"fused GEGLU {M}x{F}x{K}")
+
+
+def F_gelu(x):
+    return F.gelu(x)
+
+
+@pytest.mark.parametrize("B,HW,C", [(2, 256, 1280), (8, 64, 1280), (3, 64, 2560), (2, 256, 2560)])
+def test_groupnorm_small_map_single_launch(dev, B, HW, C):
+    from pbe_amd import ops
+    g = _g(C + HW + 1)
+    x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).half()
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.silu(F.group_norm(x.float().transpose(1, 2), 32, gamma, beta, 1e-5)).transpose(1, 2)
+    _close(ops.groupnorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True), ref, rtol=3e-3, what=f"groupnorm small C={C} HW={HW}")
+    x1, x2 = x[..., :C // 2].contiguous(), x[..., C // 2:].contiguous()
+    _close(ops.groupnorm(x1.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True, x2=x2.to(dev)), ref, rtol=3e-3, what="groupnorm small concat")
