@@ -118,10 +118,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # one process per GPU.  PBE_DIST_BACKEND=gloo + fewer GPUs than ranks is a REHEARSAL mode only
+    # (ranks share a card): it exercises the sharding / broadcast / gather code on a 1-GPU box.
+    backend = os.environ.get("PBE_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local if (backend == "nccl" or local < ndev) else local % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)          # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
 
     import cases
@@ -154,7 +162,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
