@@ -213,7 +213,8 @@ int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t B, int32_t 
 int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32_t ld, pbe_stream_t stream);
 
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
- * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1).
+ * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
+ * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2).
  */
 int pbe_tune(int32_t key, int32_t value);
 

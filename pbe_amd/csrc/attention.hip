@@ -23,14 +23,16 @@ struct AttnP {
     float scale_log2e;
 };
 
-template <int DP, int KT>
+template <int DP, int QW>
 __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
+    // QW = 32-query sub-blocks per wave (1 or 2).  QW = 2 halves the global K/V traffic, the LDS staging and the
+    // barriers per query (more work between barriers); used for long sequences where the grid still fills the chip.
+    constexpr int KT = 64;                // keys per staged tile (one barrier per tile)
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int NDS = DP / 16;          // k-steps of the QK^T product
     constexpr int NDT = DV / 32;          // 32-wide d tiles of the output
     constexpr int DC = DP / 8;            // 16-B chunks per K row
     constexpr int KSTR = (DC | 1) * 16;   // K tile row stride, bytes (odd number of 16-B units)
-    constexpr int NH = KT / 64;           // 64-key halves per staged tile (one barrier per KT keys)
     constexpr int VSTR = KT * 2 + 8;      // V^T tile row stride, bytes (8 mod 128: conflict-free ds_read_b64)
     constexpr int K_BYTES = KT * KSTR;
     constexpr int V_BYTES = DV * VSTR;
@@ -38,12 +40,13 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     constexpr int KCH = KT * DC, NKL = (KCH + 255) / 256;
     constexpr int VPR = KT / 8;           // 16-B chunks per V^T row
     constexpr int VCH = DV * VPR, NVL = (VCH + 255) / 256;
+    constexpr int BQ = 128 * QW;          // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q0 = blockIdx.x * BQ + wave * 32 * QW + l31;          // sub-block i holds query q0 + 32 i
     const int D = p.D;
     const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const h16x8 one8 = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -57,15 +60,17 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     const h16* Vb = p.VT + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
 
     // Q fragments (B operand of S^T = K Q^T): lane = query column, 8 consecutive d per k-step half
-    h16x8 qf[NDS];
+    h16x8 qf[QW][NDS];
 #pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) {
-        const int d0 = ds * 16 + 8 * h5;
-        const bool ok = q < p.Nq && d0 < D;
-        const h16* src = ok ? Qb + (long)q * p.q_rs + d0 : p.Q;
-        h16x8 v = *reinterpret_cast<const h16x8*>(src);
-        qf[ds] = ok ? v : zero8;
-    }
+    for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            const int d0 = ds * 16 + 8 * h5;
+            const bool ok = (q0 + 32 * i) < p.Nq && d0 < D;
+            const h16* src = ok ? Qb + (long)(q0 + 32 * i) * p.q_rs + d0 : p.Q;
+            h16x8 v = *reinterpret_cast<const h16x8*>(src);
+            qf[i][ds] = ok ? v : zero8;
+        }
 
     h16x8 rk[NKL], rv[NVL];
     auto load_tile = [&](int t) {
@@ -88,7 +93,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
             const h16* src = ok ? Vb + (long)row * p.vt_rs + key0 : p.VT;
             h16x8 v = *reinterpret_cast<const h16x8*>(src);
             v = ok ? v : zero8;
-            if (ONES && idx < VCH && row == DV - 1 && key0 < p.Nk) v = one8;      // denominator row (see below)
+            if (ONES && idx < VCH && row == DV - 1 && key0 < p.Nk) v = one8;      // denominator row
             if (key0 < p.Nk && key0 + 8 > p.Nk) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -119,12 +124,16 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         }
     };
 
-    f32x16 o[NDT];
+    f32x16 o[QW][NDT];
+    float m_run[QW], l_run[QW];
 #pragma unroll
-    for (int i = 0; i < NDT; ++i)
+    for (int i = 0; i < QW; ++i) {
+        m_run[i] = -INFINITY; l_run[i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][dt][r] = 0.f;
+    }
 
     const int nt = (p.Nk + KT - 1) / KT;
     load_tile(0);
@@ -136,127 +145,134 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         if (t + 1 < nt) load_tile(t + 1);
         const unsigned char* sk = smem + cur * BUF;
         const unsigned char* sv = sk + K_BYTES;
+        const int kv0 = t * KT;
 
-#pragma unroll 1
-        for (int hk = 0; hk < NH; ++hk) {
-        if (t * KT + hk * 64 >= p.Nk) break;           // staged tile padded past the last key
-        // ---- S^T = K Q^T : two 32-key sub-tiles ----
-        f32x16 s0, s1;
+        // One query sub-block at a time (registers for S / P are reused); the staged K / V^T tile, its
+        // global loads and the barrier are shared by all QW sub-blocks.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int i = 0; i < QW; ++i) {
+            // ---- S^T = K Q^T : two 32-key sub-tiles ----
+            f32x16 s0, s1;
 #pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-            const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + (hk * 64 + l31) * KSTR + (ds * 2 + h5) * 16);
-            const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (hk * 64 + 32 + l31) * KSTR + (ds * 2 + h5) * 16);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ds], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ds], s1, 0, 0, 0);
-        }
-        // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32) ----
-        // VALU budget matters here (d = 40: 14 MFMAs per tile vs ~200 VALU ops): the max runs on RAW scores,
-        // the scale is folded into the exp2 argument (one FMA), O is rescaled only when some lane's max grew.
-        const int kv0 = t * KT + hk * 64;
-        if (kv0 + 64 > p.Nk) {                          // tail tile only (wave-uniform branch, selects inside)
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
+                const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[i][ds], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[i][ds], s1, 0, 0, 0);
+            }
+            // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32) ----
+            // VALU budget matters here (d = 40: 14 MFMAs per tile vs ~200 VALU ops): the max runs on RAW scores,
+            // the scale is folded into the exp2 argument (one FMA), O is rescaled only when some lane's max grew.
+            if (kv0 + 64 > p.Nk) {                      // tail tile only (wave-uniform branch, selects inside)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+                    s0[r] = (key >= p.Nk) ? -INFINITY : s0[r];
+                    s1[r] = (key + 32 >= p.Nk) ? -INFINITY : s1[r];
+                }
+            }
+            float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[i], mx * p.scale_log2e);
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run[i]) != 0) {      // some query's running max grew in this wave
+                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);
+                m_run[i] = m_new;
+                l_run[i] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
+            }
+            const float neg_m = -m_run[i];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-                s0[r] = (key >= p.Nk) ? -INFINITY : s0[r];
-                s1[r] = (key + 32 >= p.Nk) ? -INFINITY : s1[r];
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
             }
-        }
-        float mx = fmaxf(s0[0], s1[0]);
+            if (!ONES) {
+                float psum = 0.f;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {      // some query's running max grew in this wave
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < NDT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        const float neg_m = -m_run;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
-            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
-        }
-        if (!ONES) {
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) psum += s0[r] + s1[r];
-            l_run += psum;
-        }
-
-        // ---- P^T fragments straight from the accumulator registers (permuted k order) ----
-        h16x8 pf[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pf[0][j] = (h16)s0[j];
-            pf[1][j] = (h16)s0[8 + j];
-            pf[2][j] = (h16)s1[j];
-            pf[3][j] = (h16)s1[8 + j];
-        }
-        // ---- O^T += V^T P^T ----
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + hk * 128 + 8 * h5;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {   // ks = sub*2 + s : keys sub*32 + 16 s + {4h..4h+3, 8+4h..}
-                const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow + ks * 32);
-                const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + ks * 32 + 16);
-                const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) psum += s0[r] + s1[r];
+                l_run[i] += psum;
             }
-        }
+            // ---- P^T fragments straight from the accumulator registers (permuted k order) ----
+            h16x8 pf[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pf[0][j] = (h16)s0[j];
+                pf[1][j] = (h16)s0[8 + j];
+                pf[2][j] = (h16)s1[j];
+                pf[3][j] = (h16)s1[8 + j];
+            }
+            // ---- O^T += V^T P^T ----
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + 8 * h5;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {   // ks = sub*2 + s : keys sub*32 + 16 s + {4h..4h+3, 8+4h..}
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow + ks * 32);
+                    const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + ks * 32 + 16);
+                    const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[i][dt], 0, 0, 0);
+                }
+            }
+            if (QW > 1) __builtin_amdgcn_sched_barrier(0);      // keep the sub-blocks sequential: their S / P registers are shared
         }
         if (t + 1 < nt) store_tile(cur ^ 1);
         __syncthreads();
     }
 
     // ---- normalise and store O[q, h*D + d] ----
-    float l;
-    if (ONES) {                                           // O^T row DV-1 lives in register 15 of the upper half-wave
-        const float mine = o[NDT - 1][15];
-        const float other = __shfl_xor(mine, 32, 64);
-        l = h5 ? mine : other;
-    } else {
-        l = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv = 1.0f / l;
-    if (q < p.Nq) {
-        h16* Ob = p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+    for (int i = 0; i < QW; ++i) {
+        float l;
+        if (ONES) {                                       // O^T row DV-1 lives in register 15 of the upper half-wave
+            const float mine = o[i][NDT - 1][15];
+            const float other = __shfl_xor(mine, 32, 64);
+            l = h5 ? mine : other;
+        } else {
+            l = l_run[i] + __shfl_xor(l_run[i], 32, 64);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + 32 * i;
+        if (q < p.Nq) {
+            h16* Ob = p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dt * 32 + 8 * g + 4 * h5;
-                if (d0 < D) {
-                    h16x4 v;
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (h16)(o[dt][4 * g + r] * inv);
-                    *reinterpret_cast<h16x4*>(Ob + d0) = v;
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = dt * 32 + 8 * g + 4 * h5;
+                    if (d0 < D) {
+                        h16x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (h16)(o[i][dt][4 * g + r] * inv);
+                        *reinterpret_cast<h16x4*>(Ob + d0) = v;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int DP, int KT>
+template <int DP, int QW>
 static void launch_attn(const AttnP& p, hipStream_t s) {
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int KSTR = ((DP / 8) | 1) * 16;
-    constexpr int BUF = (KT * KSTR + DV * (KT * 2 + 8) + 15) / 16 * 16;
+    constexpr int BUF = (64 * KSTR + DV * 136 + 15) / 16 * 16;
     constexpr size_t lds = 2 * BUF;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
-    hipLaunchKernelGGL((attn_kernel<DP, KT>), grid, dim3(256), lds, s, p);
+    dim3 grid(cdiv(p.Nq, 128 * QW), p.B * p.H);
+    hipLaunchKernelGGL((attn_kernel<DP, QW>), grid, dim3(256), lds, s, p);
 }
+
+int g_pbe_attn_qw = 0;       // pbe_tune(3, v): 0 = heuristic, 1 / 2 = force queries-per-wave factor
 
 extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(d && d->Q && d->K && d->VT && d->O, "pbe_attention_f16: null operand");
@@ -278,15 +294,16 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_ATTN, s);
     const int D = d->D;
-    // long sequences stage 128 keys per barrier (halves the exposed load latency); short ones 64
-    const bool big = false;   // measured: 128-key tiles halve the resident workgroups (LDS) and run 27 % slower at N=4096, d=40
-    if (D <= 16) launch_attn<16, 64>(p, s);
-    else if (D <= 32) launch_attn<32, 64>(p, s);
-    else if (D <= 48) { if (big) launch_attn<48, 128>(p, s); else launch_attn<48, 64>(p, s); }
-    else if (D <= 64) { if (big) launch_attn<64, 128>(p, s); else launch_attn<64, 64>(p, s); }
-    else if (D <= 80) { if (big) launch_attn<80, 128>(p, s); else launch_attn<80, 64>(p, s); }
-    else if (D <= 128) launch_attn<128, 64>(p, s);
-    else launch_attn<160, 64>(p, s);
+    // 64 queries per wave when the grid still covers the chip (256 CUs x ~3 resident workgroups)
+    const long blocks2 = (long)cdiv(d->Nq, 256) * d->B * d->H;
+    const bool two = g_pbe_attn_qw ? g_pbe_attn_qw == 2 : (blocks2 >= 512 && D <= 80);
+    if (D <= 16) launch_attn<16, 1>(p, s);
+    else if (D <= 32) launch_attn<32, 1>(p, s);
+    else if (D <= 48) { if (two) launch_attn<48, 2>(p, s); else launch_attn<48, 1>(p, s); }
+    else if (D <= 64) { if (two) launch_attn<64, 2>(p, s); else launch_attn<64, 1>(p, s); }
+    else if (D <= 80) { if (two) launch_attn<80, 2>(p, s); else launch_attn<80, 1>(p, s); }
+    else if (D <= 128) launch_attn<128, 1>(p, s);
+    else launch_attn<160, 1>(p, s);
     pbe_prof_end(PBE_K_ATTN, s, 4.0 * d->B * d->H * (double)d->Nq * d->Nk * d->D);
     PBE_LAUNCH_CHECK("pbe_attention_f16");
     return PBE_OK;

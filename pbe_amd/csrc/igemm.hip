@@ -426,6 +426,7 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
 extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 1) { g_pbe_force_cfg = (value >= 0 && value < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
+    if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 

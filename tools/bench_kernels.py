@@ -93,9 +93,14 @@ def bench_attn(B=8):
         H, Cc = 8, 8 * D
         qk, vt = rnd(B * N, 2 * Cc), rnd(B, Cc, N)
         fl = 4.0 * B * H * N * N * D
-        us = timeit(lambda: ops.attention(qk, qk[:, Cc:], vt, B, H, N, N, D, D ** -0.5, q_strides=(N * 2 * Cc, 2 * Cc), k_strides=(N * 2 * Cc, 2 * Cc),
-                                          vt_strides=(Cc * N, N)))
-        print(f"attn N={N:5d} D={D:3d} x{cnt}: {us:8.1f} us {fl / us / 1e6:7.1f} TF", flush=True)
+        row = f"attn N={N:5d} D={D:3d} x{cnt}:"
+        for qw in (1, 2):
+            ops.tune(3, qw)
+            us = timeit(lambda: ops.attention(qk, qk[:, Cc:], vt, B, H, N, N, D, D ** -0.5, q_strides=(N * 2 * Cc, 2 * Cc), k_strides=(N * 2 * Cc, 2 * Cc),
+                                              vt_strides=(Cc * N, N)))
+            row += f" | qw{qw}: {us:8.1f} us {fl / us / 1e6:7.1f} TF"
+        ops.tune(3, 0)
+        print(row, flush=True)
 
 
 def bench_norm(B=8):
