@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 3
+#define PBE_ABI_VERSION 4
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -76,7 +76,7 @@ typedef struct pbe_gemm_desc {
     int32_t bias_per_row;
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
-    int32_t tile_cfg;       /* -1 = built-in heuristic; 0..6 = block-tile config from a tuning table */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; 0..8 = block-tile config from a tuning table */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 
@@ -90,7 +90,7 @@ int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
  * F.interpolate + conv), :150-160 (Downsample s2 p1), :658-662,824-828 (conv in/out);
  * model.py:44-81,92-121 (VAE convs; Downsample pad (0,1,0,1) + s2 p0 == pad=0 here).
  * Requires (C1+C2) % 64 == 0 and C1 % 64 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
- * Wp is the OIHW weight re-packed by the host to [Cout, 9*Cin] (tap-major, channel-minor).
+ * Wp is the OIHW weight re-packed by the host to [Cout, 9*Cin] in (channel block, tap, channel) order — see kblock.
  * ------------------------------------------------------------------------------------------ */
 typedef struct pbe_conv3x3_desc {
     const void* X;
@@ -107,6 +107,8 @@ typedef struct pbe_conv3x3_desc {
     void* workspace;        /* optional split-K scratch, as in pbe_gemm_desc */
     size_t workspace_bytes;
     int32_t tile_cfg;       /* -1 = heuristic, else tile config index (tuning table) */
+    int32_t kblock;         /* channel block cb of Wp's K order: k = ((ci/cb)*9 + tap)*cb + ci%cb; multiple of 32 that
+                               divides C1 and C2 (0 = 32).  A pixel's 9 taps are then re-read within 9*cb/32 k-tiles (L2 hits) */
 } pbe_conv3x3_desc;
 int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
 

@@ -107,6 +107,7 @@ class ResBlock(HipModule, TimestepBlock):
         """x [B,H,W,C1] (+ skip [B,H,W,C2] = the concat partner) ; emb_out [B, Cout] = Linear(SiLU(emb))."""
         p = self.pk()
         B, H, W, C1 = x.shape
+        # GroupNorm reads the concat pair in place and writes the normalised concat as ONE tensor: the conv has a single source
         h = ops.conv3x3(ops.groupnorm(x, p.g1, p.b1, p.eps1, True, x2=skip), p.w1, p.cb1, rowvec=emb_out)
         h = ops.groupnorm(h, p.g2, p.b2, p.eps2, True)
         if p.ws is not None:

@@ -1,7 +1,7 @@
 // Implicit-GEMM on the gfx950 matrix cores: one kernel body, two activation loaders.
 //
 //   MODE 0 (dense)   C[m,n] = sum_k A[m,k] W[n,k]          Linear / 1x1 conv / bmm
-//   MODE 1 (conv3x3) m = (b,oy,ox), k = (tap, ci)          NHWC 3x3 conv gather, zero padding,
+//   MODE 1 (conv3x3) m = (b,oy,ox), k = (ci/cb, tap, ci%cb) NHWC 3x3 conv gather, zero padding,
 //                                                          optional fused nearest-2x upsample and
 //                                                          two-source channel concat
 //
@@ -36,7 +36,7 @@ struct IGemmP {
     long sA, sW, sC, sR;
     float alpha; int act; int bias_row; int vec;
     // conv gather
-    int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups;
+    int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 32)
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
 };
@@ -56,9 +56,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     constexpr int S = 4, D = S - 1;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
-    constexpr int LA = BM / 16 / NW, LW = BN / 16 / NW, LPT = LA + LW;
+    constexpr int PW = BN / 16;                       // 16-row DMA pieces of the weight tile, dealt round-robin to the waves
+    constexpr int LA = BM / 16 / NW, LW = (PW + NW - 1) / NW, LPT = LA + LW;
     constexpr int CLD = BN + 8;
-    static_assert(LA >= 1 && LW >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "loader pieces must divide over the waves");
+    static_assert(LA >= 1 && BM % (16 * NW) == 0 && BN % 16 == 0, "activation pieces must divide over the waves");
+    // When PW is not a multiple of NW (BN = 320, 8 waves) the waves left without a piece issue a dummy DMA of
+    // the zero block into a 1-KiB dump slot, so every wave's vmcnt stays uniform (LPT loads per k-tile).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,45 +83,63 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     bool a_ok[LA];
     const h16* a_row[LA];
     const h16* a_row2[LA];
-    int cb[LA], cy[LA], cx[LA];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int m = m0 + (wave * LA + i) * 16 + lrow;
         a_ok[i] = m < p.M;
-        if (MODE == 0) {
-            a_row[i] = p.A + bz * p.sA + (long)m * p.lda;
-            a_row2[i] = p.A2 ? p.A2 + (long)m * p.lda2 : p.A;
-            cb[i] = cy[i] = cx[i] = 0;
-        } else {
-            const int hw = p.Ho * p.Wo;
+        a_row[i] = p.A + bz * p.sA + (long)m * p.lda;
+        a_row2[i] = p.A2 ? p.A2 + (long)m * p.lda2 : p.A;
+    }
+    // conv: K is ordered (channel block of 32, tap, channel) so the 9 taps of a pixel's 32 channels are
+    // consecutive k-tiles — the shifted re-reads hit L2 instead of going back to the Infinity Cache / HBM
+    // (measured: tap-major order re-fetched the input 9x beyond L2).  The tap -> input-pixel map of this
+    // tile's BM rows is built once into LDS: tab[tap][row] = pixel index, or -1 outside the (virtual) image.
+    int* tab = reinterpret_cast<int*>(smem + S * STAGE);
+    unsigned char* dump = smem + S * STAGE + (MODE == 1 ? 9 * BM * 4 : 0);
+    if (MODE == 1) {
+        const int hw = p.Ho * p.Wo, Hv = p.H << p.ups, Wv = p.Wd << p.ups;
+        for (int row = tid; row < BM; row += NT) {            // one thread per tile row: one (b, oy, ox) decode, 9 taps
+            const int m = m0 + row;
+            const bool rok = m < p.M;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            cb[i] = b; cy[i] = oy * p.cstride - p.pad; cx[i] = ox * p.cstride - p.pad;
-            a_row[i] = a_row2[i] = p.A;
+            const int iy0 = oy * p.cstride - p.pad, ix0 = ox * p.cstride - p.pad;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int iy = iy0 + tp / 3, ix = ix0 + tp % 3;
+                const bool ok = rok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                tab[tp * BM + row] = ok ? (b * p.H + (iy >> p.ups)) * p.Wd + (ix >> p.ups) : -1;
+            }
         }
+        __syncthreads();
     }
     bool w_ok[LW];
     const h16* w_row[LW];
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-        const int n = n0 + (wave * LW + i) * 16 + lrow;
-        w_ok[i] = n < p.N;
+        const int pc = wave + NW * i;
+        const int n = n0 + pc * 16 + lrow;
+        w_ok[i] = pc < PW && n < p.N;
         w_row[i] = p.W + bz * p.sW + (long)(w_ok[i] ? n : 0) * p.ldw;
     }
     const int nk_all = (p.K + 31) >> 5;
-    const int Cin = p.C1 + p.C2;
     int kt0 = 0, nk = nk_all;                        // this workgroup's k-tile range [kt0, nk)
     if (p.splits > 1) {
         const int per = (nk_all + p.splits - 1) / p.splits;
         kt0 = blockIdx.z * per;
         nk = min(nk_all, kt0 + per);
     }
-    int tap = 0, c0 = 0;
-    if (MODE == 1 && kt0 > 0) { tap = (kt0 * 32) / Cin; c0 = kt0 * 32 - tap * Cin; }
+    // conv K order: (channel block of cb, tap, channel): state of the NEXT k-tile to issue
+    const int KB = MODE == 1 ? p.cb >> 5 : 1;        // k-tiles per (block, tap) visit
+    int tap = 0, c0 = 0, kj = 0;
+    if (MODE == 1 && kt0 > 0) {
+        const int per_blk = 9 * KB, cblk = kt0 / per_blk, r = kt0 - cblk * per_blk;
+        tap = r / KB; kj = r - tap * KB; c0 = cblk * p.cb + kj * 32;
+    }
     const h16* a_src[LA];
-    bool a_val[LA];
+    bool fresh = true;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) { a_src[i] = zsrc; a_val[i] = false; }
+    for (int i = 0; i < LA; ++i) a_src[i] = zsrc;
 
     auto issue = [&](int kt) {
         unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
@@ -133,31 +154,33 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
             }
         } else {
-            // the gather address is recomputed only when the tap (or the concat source) changes;
-            // inside a tap consecutive k-tiles are +32 channels of the same pixel
-            if (c0 == 0 || c0 == p.C1 || kt == kt0) {
-                const int dy = tap / 3, dx = tap - 3 * dy;
-                const int Hv = p.H << p.ups, Wv = p.Wd << p.ups;
+            if (kj == 0 || fresh) {                   // new (block, tap): look the pixels up; otherwise +32 channels
+                fresh = false;
+                const bool first = c0 < p.C1;         // which concat source this channel block lives in (uniform)
+                const h16* base = first ? p.A + c0 + gch * 8 : p.A2 + (c0 - p.C1) + gch * 8;
+                const long cs = first ? p.C1 : p.C2;
 #pragma unroll
                 for (int i = 0; i < LA; ++i) {
-                    const int iy = cy[i] + dy, ix = cx[i] + dx;
-                    a_val[i] = a_ok[i] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                    const long pix = ((long)cb[i] * p.H + (iy >> p.ups)) * p.Wd + (ix >> p.ups);
-                    a_src[i] = (c0 < p.C1) ? p.A + pix * p.C1 + c0 + gch * 8 : p.A2 + pix * p.C2 + (c0 - p.C1) + gch * 8;
+                    const int pix = tab[tap * BM + (wave * LA + i) * 16 + lrow];
+                    a_src[i] = pix >= 0 ? base + (long)pix * cs : nullptr;
                 }
             }
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                PBE_GLDS16(a_val[i] ? a_src[i] : zsrc, sa + (wave * LA + i) * 1024);
-                a_src[i] += 32;
+                PBE_GLDS16(a_src[i] ? a_src[i] : zsrc, sa + (wave * LA + i) * 1024);
+                if (a_src[i]) a_src[i] += 32;
             }
             c0 += 32;
-            if (c0 >= Cin) { c0 = 0; ++tap; }
+            if (++kj == KB) {
+                kj = 0;
+                if (++tap == 9) tap = 0; else c0 -= p.cb;      // next tap of the same block, or first tap of the next block
+            }
         }
 #pragma unroll
         for (int i = 0; i < LW; ++i) {
             const h16* src = (w_ok[i] && kok) ? w_row[i] + k : zsrc;
-            PBE_GLDS16(src, sw + (wave * LW + i) * 1024);
+            const int pc = wave + NW * i;
+            PBE_GLDS16(src, (PW % NW == 0 || pc < PW) ? sw + pc * 1024 : dump);
         }
     };
 
@@ -340,7 +363,9 @@ struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
 // eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP)
 static const TileCfg kCfg[] = {
     {256, 256, 2, 4, 1, 1.00}, {256, 128, 4, 2, 1, 0.80}, {128, 256, 2, 4, 1, 0.80},
-    {128, 128, 2, 2, 2, 0.60}, {128, 64, 2, 2, 2, 0.48}, {64, 128, 2, 2, 2, 0.48}, {64, 64, 2, 2, 2, 0.36}};
+    {128, 128, 2, 2, 2, 0.60}, {128, 64, 2, 2, 2, 0.48}, {64, 128, 2, 2, 2, 0.48}, {64, 64, 2, 2, 2, 0.36},
+    {256, 320, 2, 4, 1, 1.04},           // N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
+    {128, 320, 2, 4, 1, 0.82}};          // same, half the rows: fills the chip when M / 256 < 256 tiles
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index) forces a tile config; -1 = heuristic
@@ -363,7 +388,7 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // Shallow-K problems are dominated by the prologue / epilogue and by HBM traffic, where many small
 // workgroups beat few large ones (measured, tools/bench_kernels.py); deep-K problems by staged
 // bytes per FLOP.  pbe_amd/tuned_mi355x.json overrides this per shape (desc.tile_cfg).
-static const double kEffShallow[] = {0.45, 0.70, 0.70, 0.85, 1.00, 0.95, 0.80};
+static const double kEffShallow[] = {0.45, 0.70, 0.70, 0.85, 1.00, 0.95, 0.80, 0.45, 0.60};
 
 static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg) {
     Plan best{3, 1};
@@ -392,7 +417,8 @@ template <int BM, int BN, int NWM, int NWN, int MODE>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     constexpr size_t ring = 4 * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
-    constexpr size_t lds = ring > c_bytes ? ring : c_bytes;
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE>),
@@ -419,6 +445,8 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
         case 3: launch_cfg<128, 128, 2, 2, MODE>(p, batch, s); break;
         case 4: launch_cfg<128, 64, 2, 2, MODE>(p, batch, s); break;
         case 5: launch_cfg<64, 128, 2, 2, MODE>(p, batch, s); break;
+        case 7: launch_cfg<256, 320, 2, 4, MODE>(p, batch, s); break;
+        case 8: launch_cfg<128, 320, 2, 4, MODE>(p, batch, s); break;
         default: launch_cfg<64, 64, 2, 2, MODE>(p, batch, s); break;
     }
 }
@@ -497,6 +525,8 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     p.vec = (d->Cout % 8 == 0) && (!d->resid || al16(d->resid));
     p.H = d->H; p.Wd = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Ho = Ho; p.Wo = Wo;
     p.cstride = d->stride; p.pad = d->pad; p.ups = d->upsample;
+    p.cb = d->kblock > 0 ? d->kblock : 32;
+    PBE_REQUIRE(p.cb % 32 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "pbe_conv3x3_f16: kblock=%d must be a multiple of 32 dividing C1=%d and C2=%d", p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_CONV3, s);

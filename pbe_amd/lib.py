@@ -8,7 +8,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbe_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -27,7 +27,7 @@ class Conv3x3Desc(C.Structure):
     _fields_ = [("X", c_vp), ("X2", c_vp), ("Wp", c_vp), ("Y", c_vp), ("bias", c_vp), ("rowvec", c_vp), ("resid", c_vp),
                 ("B", c_i32), ("H", c_i32), ("W", c_i32), ("C1", c_i32), ("C2", c_i32), ("Cout", c_i32),
                 ("stride", c_i32), ("pad", c_i32), ("upsample", c_i32), ("ldv", c_i32), ("act", c_i32),
-                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32)]
+                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32), ("kblock", c_i32)]
 
 
 class AttnDesc(C.Structure):

@@ -174,7 +174,7 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
         _f(bias, "conv3x3 bias")
     d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
                        1 if upsample else 0, ldv, act, _splitk_ws(x.device).data_ptr(), SPLITK_WS_BYTES,
-                       _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"))
+                       _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"), conv_kblock(C1, C2))
     _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
     return y
 
@@ -365,14 +365,33 @@ def bcast_row(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, B: int, y_bs:
 
 
 # ---- weight packing (one-off, at load time) ---------------------------------------------------
-def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
-    """OIHW fp32 -> [Cout, 9*Cin] fp16, k = (ky*3+kx)*Cin + ci (optionally zero-padding Cin)."""
+def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """OIHW fp32 -> packed fp16 [Cout, 9*Cin] in the K order the kernels gather in.
+    * cin_pad is None (Cin % 32 == 0, implicit-GEMM conv): k = ((ci // cb) * 9 + ky*3+kx) * cb + ci % cb with
+      cb = conv_kblock(Cin) — channel-block major, tap minor, so a pixel's 9 shifted reads stay within 9*cb/32
+      k-tiles of each other (L2 reuse) while cb/32 consecutive k-tiles walk the same pixel (+32 channels).
+    * cin_pad given (tiny Cin, im2col + GEMM path): k = (ky*3+kx) * cin_pad + ci, zero-padded channels."""
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    wp = w.permute(0, 2, 3, 1)
-    if cin_pad is not None and cin_pad != ci:
-        wp = torch.nn.functional.pad(wp, (0, cin_pad - ci))
-    return wp.reshape(co, -1).to(torch.float16).contiguous()
+    wp = w.permute(0, 2, 3, 1)                                   # [Co, 3, 3, Ci]
+    if cin_pad is not None:
+        if cin_pad != ci:
+            wp = torch.nn.functional.pad(wp, (0, cin_pad - ci))
+        return wp.reshape(co, -1).to(torch.float16).contiguous()
+    assert ci % 32 == 0, "implicit-GEMM conv needs Cin % 32 == 0 (use cin_pad for the im2col path)"
+    cb = conv_kblock(*(split if split else (ci, 0)))       # split = (C1, C2) when the conv reads a channel concat
+    assert not split or sum(split) == ci
+    wp = wp.reshape(co, 9, ci // cb, cb).permute(0, 2, 1, 3)      # [Co, Ci/cb, 9, cb]
+    return wp.reshape(co, 9 * ci).to(torch.float16).contiguous()
+
+
+def conv_kblock(c1: int, c2: int = 0) -> int:
+    """Channel block of the conv K order for a layer whose input is c1 (+ c2 concatenated) channels
+    (deterministic, shared by pack_conv3x3 and conv3x3): the largest of 160 / 128 / 64 / 32 dividing both."""
+    for cb in (160, 128, 64, 32):
+        if c1 % cb == 0 and c2 % cb == 0:
+            return cb
+    raise _l.PbeError(f"conv: C1={c1} / C2={c2} are not multiples of 32")
 
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:

@@ -160,7 +160,7 @@ def test_conv3x3_concat_rowvec_resid(dev):
     emb = torch.randn(B, Co + 64, generator=g).half()          # rowvec taken as a column slice of a wider buffer
     res = torch.randn(B, H, W, Co, generator=g).half()
     ref = (_conv_ref(x1, w, b, 1, 1, False, x2) + emb[:, 64:].float()[:, None, None, :]).half().float() + res.float()
-    got = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w.float()).to(dev), b.to(dev), x2=x2.to(dev), rowvec=emb.to(dev)[:, 64:], resid=res.to(dev))
+    got = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w.float(), split=(C1, C2)).to(dev), b.to(dev), x2=x2.to(dev), rowvec=emb.to(dev)[:, 64:], resid=res.to(dev))
     _close(got, ref, what="conv3x3 concat+emb+resid")
 
 

@@ -23,7 +23,7 @@ import torch  # noqa: E402
 from pbe_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-NCFG = 7
+NCFG = 9
 
 
 def timeit(fn, iters, warm=2):
