@@ -1,18 +1,23 @@
 // Fused multi-head attention forward, softmax(Q K^T * scale) V, for gfx950 (wave64, MFMA 32x32x16 f16).
 //
-// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries for the
-// whole K/V sweep.  K/V^T tiles of 64 keys are staged global -> registers -> LDS (next tile's
-// loads in flight under the current tile's MFMAs, two LDS buffers, one barrier per tile).
+// One workgroup = 4 waves = 128 (or 256) queries of one (batch, head); each wave owns 32 (or 64)
+// queries for the whole K/V sweep.  K / V^T tiles of 64 keys go global -> LDS by LDS-DMA
+// (global_load_lds, 16 B per lane, no VGPR staging, no ds_write): the per-lane source pointers are
+// computed once and advance by a constant per tile, so the staging costs ~3 VALU ops per 1 KB.
+// Two LDS buffers, tile t+1 in flight under tile t's MFMAs, one barrier per tile.
 //
 // The score tile is computed TRANSPOSED, S^T = K Q^T, so the query index sits on the lane
 // (column of the 32x32 accumulator) and the 32 keys of a sub-tile sit in the lane's registers:
 // the row max / row sum are register-local plus ONE cross-half exchange, and the exponentiated
 // accumulator registers feed the second product O^T = V^T P^T directly as its B operand (no LDS
-// round trip, no shuffles) — the k order inside each 16-key step is permuted
-// (key = 16s + 8(j>>2) + 4h + (j&3)), so the V^T fragment is read with the same permutation.
-// V therefore arrives already transposed ([head*D + d][key], produced for free by the
-// projection GEMM with swapped operands), its tile rows padded to 136 B (conflict-free
-// ds_read_b64); K tile rows padded to an odd number of 16-B units (conflict-free ds_read_b128).
+// round trip, no shuffles).  A 32x32 accumulator keeps rows {4h..4h+3, 8+4h.., 16+4h.., 24+4h..}
+// in half-wave h; the K tile is therefore staged with its rows PERMUTED (the DMA source address is
+// per lane, so this is free): LDS row 4q+a of every 16-row group holds key 4*pi(q)+a, pi = (0,2,1,3).
+// With that, the 8 accumulator registers a lane feeds to one PV k-step are keys 16s + 8h + 0..7 in
+// natural order, and the matching V^T fragment is ONE 16-byte LDS read.
+// V arrives already transposed ([head*D + d][key], produced for free by the projection GEMM with
+// swapped operands).  Tile rows are padded to an odd number of 16-B slots (K: DP/8 | 1, V^T: 9):
+// conflict-free ds_read_b128; the pad slots and the d-padding are zeroed once and never written.
 #include "common.h"
 #include "../../include/pbe_hip.h"
 
@@ -23,24 +28,41 @@ struct AttnP {
     float scale_log2e;
 };
 
-template <int DP, int QW>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
+#define PBE_GLDS16(gsrc, ldst)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),         \
+                                     (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+
+template <int DP>
+struct AttnTile {
+    static constexpr int KT = 64;                 // keys per staged tile (one barrier per tile)
+    static constexpr int DV = (DP + 31) / 32 * 32;
+    static constexpr int DC = DP / 8;             // 16-B chunks per K row
+    static constexpr int KR = DC | 1;             // slots per K row (odd)
+    static constexpr int VR = KT / 8 + 1;         // slots per V^T row (odd)
+    static constexpr int KSTR = KR * 16, VSTR = VR * 16;
+    static constexpr int KSLOTS = KT * KR, VSLOTS = DV * VR, SLOTS = KSLOTS + VSLOTS;
+    static constexpr int NI = (SLOTS + 63) / 64;  // LDS-DMA instructions (64 slots each) per tile
+    static constexpr int NPW = (NI + 3) / 4;      // ... per wave
+    static constexpr int BUF = NI * 1024;         // bytes per buffer
+};
+
+// key held by LDS row r of the K tile (middle quads of every 16 rows swapped)
+__device__ __forceinline__ int attn_key_of_row(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <int DP, int QW, int KH>
+__global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kernel(const AttnP p) {
     // QW = 32-query sub-blocks per wave (1 or 2).  QW = 2 halves the global K/V traffic, the LDS staging and the
     // barriers per query (more work between barriers); used for long sequences where the grid still fills the chip.
-    constexpr int KT = 64;                // keys per staged tile (one barrier per tile)
-    constexpr int DV = (DP + 31) / 32 * 32;
+    // KH = 64-key tiles staged per barrier (1 or 2): the 4 waves of a workgroup sit on 4 different SIMDs and
+    // re-synchronise at every barrier, so fewer barriers means less time lost to the slowest wave.
+    using T = AttnTile<DP>;
+    constexpr int KT = T::KT, DV = T::DV, KR = T::KR, VR = T::VR, KSTR = T::KSTR, VSTR = T::VSTR;
+    constexpr int KSLOTS = T::KSLOTS, SLOTS = T::SLOTS, NI = T::NI, NPW = T::NPW, BUF = T::BUF;
+    constexpr int K_BYTES = KSLOTS * 16;
     constexpr int NDS = DP / 16;          // k-steps of the QK^T product
     constexpr int NDT = DV / 32;          // 32-wide d tiles of the output
-    constexpr int DC = DP / 8;            // 16-B chunks per K row
-    constexpr int KSTR = (DC | 1) * 16;   // K tile row stride, bytes (odd number of 16-B units)
-    constexpr int VSTR = KT * 2 + 8;      // V^T tile row stride, bytes (8 mod 128: conflict-free ds_read_b64)
-    constexpr int K_BYTES = KT * KSTR;
-    constexpr int V_BYTES = DV * VSTR;
-    constexpr int BUF = (K_BYTES + V_BYTES + 15) / 16 * 16;
-    constexpr int KCH = KT * DC, NKL = (KCH + 255) / 256;
-    constexpr int VPR = KT / 8;           // 16-B chunks per V^T row
-    constexpr int VCH = DV * VPR, NVL = (VCH + 255) / 256;
     constexpr int BQ = 128 * QW;          // queries per workgroup
+    constexpr int NSLOT = 2 * KH;         // tile images in LDS: one group of KH in use, one in flight
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,6 +81,63 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     const h16* Kb = p.K + (long)b * p.k_bs + (long)h * D;
     const h16* Vb = p.VT + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
 
+    // ---- LDS init: zero every tile image (pad slots, d padding), then the ones rows ----
+    for (int i = tid; i < NSLOT * BUF / 16; i += 256) *reinterpret_cast<h16x8*>(smem + i * 16) = zero8;
+    __syncthreads();
+    if (ONES && tid < 8 * NSLOT)
+        *reinterpret_cast<h16x8*>(smem + (tid >> 3) * BUF + K_BYTES + (DV - 1) * VSTR + (tid & 7) * 16) = one8;
+
+    // ---- per-lane DMA sources: slot (j*4 + wave)*64 + lane of the tile image, advanced by a constant per tile ----
+    const h16* src[NPW];
+    int inc[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int slot = (j * 4 + wave) * 64 + lane;
+        src[j] = nullptr; inc[j] = 0;
+        if (slot < KSLOTS) {
+            const int row = slot / KR, c = slot - row * KR;
+            if (c * 8 < D) { src[j] = Kb + (long)attn_key_of_row(row) * p.k_rs + c * 8; inc[j] = KT * (int)p.k_rs; }
+        } else if (slot < SLOTS) {
+            const int sv = slot - KSLOTS, row = sv / VR, c = sv - row * VR;
+            if (c < KT / 8 && row < D) { src[j] = Vb + (long)row * p.vt_rs + c * 8; inc[j] = KT; }
+        }
+    }
+    const int nt = (p.Nk + KT - 1) / KT;
+    const int rem = p.Nk - (nt - 1) * KT;                 // keys in the last tile (1..64)
+    auto issue_tile = [&](int t, int buf) {
+        unsigned char* dst = smem + buf * BUF + wave * 1024;
+        if (t + 1 < nt || rem == KT) {                    // full tile: constant-stride pointers
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                if (src[j]) PBE_GLDS16(src[j], dst + j * 4096);
+                src[j] += inc[j];
+            }
+        } else {                                          // ragged last tile: clamp K rows, skip V^T chunks past Nk
+            const int kv0 = t * KT;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int slot = (j * 4 + wave) * 64 + lane;
+                const h16* s = nullptr;
+                if (slot < KSLOTS) {
+                    const int row = slot / KR, c = slot - row * KR;
+                    const int key = min(kv0 + attn_key_of_row(row), p.Nk - 1);
+                    if (c * 8 < D) s = Kb + (long)key * p.k_rs + c * 8;
+                } else if (slot < SLOTS) {
+                    const int sv = slot - KSLOTS, row = sv / VR, c = sv - row * VR;
+                    if (c < KT / 8 && row < D && kv0 + c * 8 < p.Nk) s = Vb + (long)row * p.vt_rs + kv0 + c * 8;
+                }
+                if (s) PBE_GLDS16(s, dst + j * 4096);
+            }
+        }
+    };
+    auto fix_tail = [&](int buf) {                        // V^T columns past the last key -> 0 (P there is 0, 0 * garbage must stay 0)
+        unsigned char* sv = smem + buf * BUF + K_BYTES;
+        for (int i = tid; i < DV * KT; i += 256) {
+            const int row = i >> 6, col = i & 63;
+            if (col >= rem) *reinterpret_cast<h16*>(sv + row * VSTR + col * 2) = (h16)0.f;
+        }
+    };
+
     // Q fragments (B operand of S^T = K Q^T): lane = query column, 8 consecutive d per k-step half
     h16x8 qf[QW][NDS];
 #pragma unroll
@@ -67,62 +146,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
         for (int ds = 0; ds < NDS; ++ds) {
             const int d0 = ds * 16 + 8 * h5;
             const bool ok = (q0 + 32 * i) < p.Nq && d0 < D;
-            const h16* src = ok ? Qb + (long)(q0 + 32 * i) * p.q_rs + d0 : p.Q;
-            h16x8 v = *reinterpret_cast<const h16x8*>(src);
+            const h16* qsrc = ok ? Qb + (long)(q0 + 32 * i) * p.q_rs + d0 : p.Q;
+            h16x8 v = *reinterpret_cast<const h16x8*>(qsrc);
             qf[i][ds] = ok ? v : zero8;
         }
-
-    h16x8 rk[NKL], rv[NVL];
-    auto load_tile = [&](int t) {
-        const int kv0 = t * KT;
-#pragma unroll
-        for (int i = 0; i < NKL; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / DC, ch = idx - row * DC;
-            const bool ok = idx < KCH && (kv0 + row) < p.Nk && ch * 8 < D;
-            const h16* src = ok ? Kb + (long)(kv0 + row) * p.k_rs + ch * 8 : p.K;
-            h16x8 v = *reinterpret_cast<const h16x8*>(src);
-            rk[i] = ok ? v : zero8;
-        }
-#pragma unroll
-        for (int i = 0; i < NVL; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / VPR, ch = idx - row * VPR;
-            const int key0 = kv0 + ch * 8;
-            const bool ok = idx < VCH && row < D && key0 < p.Nk;
-            const h16* src = ok ? Vb + (long)row * p.vt_rs + key0 : p.VT;
-            h16x8 v = *reinterpret_cast<const h16x8*>(src);
-            v = ok ? v : zero8;
-            if (ONES && idx < VCH && row == DV - 1 && key0 < p.Nk) v = one8;      // denominator row
-            if (key0 < p.Nk && key0 + 8 > p.Nk) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (key0 + e >= p.Nk) v[e] = (h16)0.f;
-            }
-            rv[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sk = smem + buf * BUF;
-        unsigned char* sv = sk + K_BYTES;
-#pragma unroll
-        for (int i = 0; i < NKL; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / DC, ch = idx - row * DC;
-            if (idx < KCH) *reinterpret_cast<h16x8*>(sk + row * KSTR + ch * 16) = rk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NVL; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / VPR, ch = idx - row * VPR;
-            if (idx < VCH) {
-                h16x4 lo = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
-                h16x4 hi = {rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
-                *reinterpret_cast<h16x4*>(sv + row * VSTR + ch * 16) = lo;
-                *reinterpret_cast<h16x4*>(sv + row * VSTR + ch * 16 + 8) = hi;
-            }
-        }
-    };
 
     f32x16 o[QW][NDT];
     float m_run[QW], l_run[QW];
@@ -135,95 +162,147 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
             for (int r = 0; r < 16; ++r) o[i][dt][r] = 0.f;
     }
 
-    const int nt = (p.Nk + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    __syncthreads();                                      // init stores done before any DMA lands on them
+#pragma unroll
+    for (int j = 0; j < KH; ++j)
+        if (j < nt) issue_tile(j, j);
+    __syncthreads();                                      // (drains vmcnt) the first group landed for every wave
+    if (nt <= KH && rem < KT) { fix_tail(nt - 1); __syncthreads(); }
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
-        const unsigned char* sk = smem + cur * BUF;
-        const unsigned char* sv = sk + K_BYTES;
-        const int kv0 = t * KT;
-
-        // One query sub-block at a time (registers for S / P are reused); the staged K / V^T tile, its
-        // global loads and the barrier are shared by all QW sub-blocks.
+    // ---- the phases of one (tile, 32-query sub-block) unit ----
+    // K / V^T fragments are fetched from LDS into registers ONCE per tile (shared by the QW sub-blocks) and EARLY:
+    // the V^T reads are issued before the softmax they hide under, the next tile's K reads right after the barrier.
+    // (Fetching each fragment just before its MFMA costs an exposed LDS round trip per MFMA: 14 per unit.)
+    constexpr bool PREF = DP <= 64, PREFV = DP <= 80;      // fragment registers: K 8 NDS, V^T 16 NDT VGPRs
+    f32x16 sc[2];                                          // S^T accumulators of the two 32-key halves
+    h16x8 pf[4];
+    h16x8 kf[PREF ? 2 : 1][PREF ? NDS : 1];
+    h16x8 vf[PREFV ? NDT : 1][4];
+    auto load_k = [&](const unsigned char* sk) {
 #pragma unroll
-        for (int i = 0; i < QW; ++i) {
-            // ---- S^T = K Q^T : two 32-key sub-tiles ----
-            f32x16 s0, s1;
+        for (int ds = 0; ds < NDS; ++ds) {
+            kf[0][ds] = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
+            kf[1][ds] = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+        }
+    };
+    auto load_v = [&](const unsigned char* sv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int ds = 0; ds < NDS; ++ds) {
+            for (int ks = 0; ks < 4; ++ks)
+                vf[dt][ks] = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);
+    };
+    auto qk = [&](int i, const unsigned char* sk) {        // S^T = K Q^T : two 32-key sub-tiles
+        f32x16& s0 = sc[0];
+        f32x16& s1 = sc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            if (PREF) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ds], qf[i][ds], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ds], qf[i][ds], s1, 0, 0, 0);
+            } else {
                 const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
                 const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[i][ds], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[i][ds], s1, 0, 0, 0);
             }
-            // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32) ----
-            // VALU budget matters here (d = 40: 14 MFMAs per tile vs ~200 VALU ops): the max runs on RAW scores,
-            // the scale is folded into the exp2 argument (one FMA), O is rescaled only when some lane's max grew.
-            if (kv0 + 64 > p.Nk) {                      // tail tile only (wave-uniform branch, selects inside)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-                    s0[r] = (key >= p.Nk) ? -INFINITY : s0[r];
-                    s1[r] = (key + 32 >= p.Nk) ? -INFINITY : s1[r];
-                }
-            }
-            float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[i], mx * p.scale_log2e);
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run[i]) != 0) {      // some query's running max grew in this wave
-                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);
-                m_run[i] = m_new;
-                l_run[i] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
-            }
-            const float neg_m = -m_run[i];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
-                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
-            }
-            if (!ONES) {
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) psum += s0[r] + s1[r];
-                l_run[i] += psum;
-            }
-            // ---- P^T fragments straight from the accumulator registers (permuted k order) ----
-            h16x8 pf[4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pf[0][j] = (h16)s0[j];
-                pf[1][j] = (h16)s0[8 + j];
-                pf[2][j] = (h16)s1[j];
-                pf[3][j] = (h16)s1[8 + j];
-            }
-            // ---- O^T += V^T P^T ----
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const unsigned char* vrow = sv + (dt * 32 + l31) * VSTR + 8 * h5;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {   // ks = sub*2 + s : keys sub*32 + 16 s + {4h..4h+3, 8+4h..}
-                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow + ks * 32);
-                    const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + ks * 32 + 16);
-                    const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[i][dt], 0, 0, 0);
-                }
-            }
-            if (QW > 1) __builtin_amdgcn_sched_barrier(0);      // keep the sub-blocks sequential: their S / P registers are shared
         }
-        if (t + 1 < nt) store_tile(cur ^ 1);
-        __syncthreads();
+    };
+    // Online softmax over this lane's 32 keys (+ the other half-wave's 32).  The VALU budget matters (d = 40: 14 MFMAs
+    // per unit vs ~130 VALU ops): the max runs on RAW scores, the scale is folded into the exp2 argument (one FMA),
+    // O is rescaled only when some lane's max grew.  Leaves P^T in pf[]: pf[ks] = keys 16 ks + 8 h + 0..7.
+    auto softmax = [&](int i, int kv0) {
+        f32x16& s0 = sc[0];
+        f32x16& s1 = sc[1];
+        if (kv0 + KT > p.Nk) {                          // ragged last tile only (wave-uniform branch)
+            int left = p.Nk - kv0 - 8 * h5;             // keys left from this half-wave's first key
+            asm volatile("" : "+v"(left));              // pins the 32 compares inside the branch (else they are hoisted into every tile)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {              // register r of half-wave h: key 16 (r >> 3) + 8 h + (r & 7)
+                const int k = 16 * (r >> 3) + (r & 7);
+                s0[r] = (k >= left) ? -INFINITY : s0[r];
+                s1[r] = (k + 32 >= left) ? -INFINITY : s1[r];
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[i], mx * p.scale_log2e);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run[i]) != 0) {      // some query's running max grew in this wave
+            const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);
+            m_run[i] = m_new;
+            l_run[i] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
+        }
+        const float neg_m = -m_run[i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
+        }
+        if (!ONES) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += s0[r] + s1[r];
+            l_run[i] += psum;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pf[0][j] = (h16)s0[j];
+            pf[1][j] = (h16)s0[8 + j];
+            pf[2][j] = (h16)s1[j];
+            pf[3][j] = (h16)s1[8 + j];
+        }
+    };
+    auto pv = [&](int i, const unsigned char* sv) {        // O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (PREFV) {
+                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][ks], pf[ks], o[i][dt], 0, 0, 0);
+                } else {
+                    const h16x8 v = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);
+                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, pf[ks], o[i][dt], 0, 0, 0);
+                }
+            }
+    };
+    // one staged tile: every sub-block's S -> softmax -> PV; `next_k` = K image of the next tile when it is already in LDS
+    auto tile = [&](int t, const unsigned char* next_k) {
+        const unsigned char* sk = smem + (t % NSLOT) * BUF;
+        const unsigned char* sv = sk + K_BYTES;
+        const int kv0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            qk(i, sk);
+            if (PREFV && i == 0) load_v(sv);                 // in flight under the first softmax
+            if (PREF && i == QW - 1 && next_k) load_k(next_k);   // the S MFMAs above were the last readers of kf
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(i, kv0);
+            pv(i, sv);
+            __builtin_amdgcn_sched_barrier(0);              // sub-blocks stay sequential: their S / P registers are shared
+        }
+    };
+
+    if (PREF) load_k(smem);
+    for (int g = 0; g * KH < nt; ++g) {
+        const int t0 = g * KH;
+#pragma unroll
+        for (int j = 0; j < KH; ++j)
+            if (t0 + KH + j < nt) issue_tile(t0 + KH + j, (t0 + KH + j) % NSLOT);
+#pragma unroll
+        for (int j = 0; j < KH; ++j)
+            if (t0 + j < nt) tile(t0 + j, (j + 1 < KH && t0 + j + 1 < nt) ? smem + ((t0 + j + 1) % NSLOT) * BUF : nullptr);
+        __syncthreads();                                  // all waves done with this group; (vmcnt drained) the next group landed
+        if (rem < KT && nt - 1 >= t0 + KH && nt - 1 < t0 + 2 * KH) { fix_tail((nt - 1) % NSLOT); __syncthreads(); }
+        if (PREF && t0 + KH < nt) load_k(smem + ((t0 + KH) % NSLOT) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- normalise and store O[q, h*D + d] ----
@@ -257,19 +336,17 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnP p) {
     }
 }
 
-template <int DP, int QW>
+template <int DP, int QW, int KH = 1>
 static void launch_attn(const AttnP& p, hipStream_t s) {
-    constexpr int DV = (DP + 31) / 32 * 32;
-    constexpr int KSTR = ((DP / 8) | 1) * 16;
-    constexpr int BUF = (64 * KSTR + DV * 136 + 15) / 16 * 16;
-    constexpr size_t lds = 2 * BUF;
+    constexpr size_t lds = 2 * KH * AttnTile<DP>::BUF;
+    static_assert(lds <= 160 * 1024, "attention tile exceeds the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(p.Nq, 128 * QW), p.B * p.H);
-    hipLaunchKernelGGL((attn_kernel<DP, QW>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_kernel<DP, QW, KH>), grid, dim3(256), lds, s, p);
 }
 
 int g_pbe_attn_qw = 0;       // pbe_tune(3, v): 0 = heuristic, 1 / 2 = force queries-per-wave factor
@@ -299,7 +376,7 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     const bool two = g_pbe_attn_qw ? g_pbe_attn_qw == 2 : (blocks2 >= 512 && D <= 80);
     if (D <= 16) launch_attn<16, 1>(p, s);
     else if (D <= 32) launch_attn<32, 1>(p, s);
-    else if (D <= 48) { if (two) launch_attn<48, 2>(p, s); else launch_attn<48, 1>(p, s); }
+    else if (D <= 48) { if (g_pbe_attn_qw == 3) launch_attn<48, 2, 2>(p, s); else if (two) launch_attn<48, 2>(p, s); else launch_attn<48, 1>(p, s); }
     else if (D <= 64) { if (two) launch_attn<64, 2>(p, s); else launch_attn<64, 1>(p, s); }
     else if (D <= 80) { if (two) launch_attn<80, 2>(p, s); else launch_attn<80, 1>(p, s); }
     else if (D <= 128) launch_attn<128, 1>(p, s);

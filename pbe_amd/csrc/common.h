@@ -39,9 +39,23 @@ void pbe_prof_end(int klass, hipStream_t s, double work);
 enum { PBE_K_CONV3 = 0, PBE_K_GEMM = 1, PBE_K_ATTN = 2, PBE_K_GNORM = 3, PBE_K_LNORM = 4, PBE_K_ELEM = 5, PBE_K_SOFTMAX = 6, PBE_K_COUNT = 7 };
 
 // ---- device helpers -------------------------------------------------------------------------
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }              // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }            // v_exp_f32
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.702f * 1.4426950408889634f * x)); }
+// exact (erf) GELU as x * Phi(x), Phi through erfc's rational-exponential form (Abramowitz & Stegun
+// 7.1.26, |err| <= 1.5e-7 on erfc): one v_rcp + one v_exp + 8 FMAs, no cancellation in the negative
+// tail.  |gelu error| < 5e-7 absolute, far below the fp16 rounding of the stored result.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = 0.5f * p * t * fast_exp2(x * x * (-0.5f * 1.4426950408889634f));
+    return x * (x < 0.0f ? q : 1.0f - q);
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
@@ -66,9 +80,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // activation on a register quad with ONE uniform branch per quad (keeps unrolled epilogues small)
 __device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
     if (act == 1 || act == 3) {
-        const float k = act == 1 ? 1.0f : 1.702f;
+        const float k = (act == 1 ? 1.0f : 1.702f) * 1.4426950408889634f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-k * v[r]));
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * fast_rcp(1.0f + fast_exp2(-k * v[r]));
     } else if (act == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);

@@ -54,6 +54,26 @@ try:
 except (OSError, ValueError):
     _TUNED = {}
 _RECORD = None            # set to a dict by tools/autotune.py to collect the shapes a workload uses
+_TIMES = None             # set to a dict by tools/shape_profile.py: key -> [(start event, end event), ...] around each launch
+
+
+class _timed:
+    """Bracket one launch with events when shape profiling is on (no-op otherwise)."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _TIMES is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _TIMES is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMES.setdefault(self.key, []).append((self.e0, e1))
+        return False
 
 
 def _tile_cfg(key: str) -> int:
@@ -131,7 +151,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d = _l.GemmDesc(_p(a), _p(a2), _p(w), _p(_h(out, "gemm out")), _p(bias), _p(rowvec), _p(resid), M, N, K, K1, lda, lda2, ldw, ldc, ldr,
                     ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0,
                     _splitk_ws(a.device).data_ptr(), SPLITK_WS_BYTES, _tile_cfg(f"g:{M}:{N}:{K}:{batch}"))
-    _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
+    with _timed(f"g:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}{'v' if rowvec is not None else ''}"):
+        _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
     return out
 
 
@@ -175,7 +196,8 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
     d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
                        1 if upsample else 0, ldv, act, _splitk_ws(x.device).data_ptr(), SPLITK_WS_BYTES,
                        _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"), conv_kblock(C1, C2))
-    _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
+    with _timed(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"):
+        _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
     return y
 
 
@@ -215,8 +237,9 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         ws = torch.empty(max(need, 1 << 21), dtype=torch.uint8, device=x.device)
         _ws[key] = ws
     y = torch.empty(tuple(x.shape[:-1]) + (C1 + C2,), dtype=torch.float16, device=x.device)
-    _l.check(lib.pbe_groupnorm_f16(_p(x), _p(x2), _p(gamma), _p(beta), _p(y), B, HW, C1, C2, groups, float(eps), 1 if silu else 0,
-                                   _p(ws), ws.numel(), _stream()), "pbe_groupnorm_f16")
+    with _timed(f"n:{B}:{HW}:{C1}:{C2}"):
+        _l.check(lib.pbe_groupnorm_f16(_p(x), _p(x2), _p(gamma), _p(beta), _p(y), B, HW, C1, C2, groups, float(eps), 1 if silu else 0,
+                                       _p(ws), ws.numel(), _stream()), "pbe_groupnorm_f16")
     return y
 
 
@@ -225,7 +248,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     x2 = x.reshape(-1, x.shape[-1])
     rows, Cc, ldx = _rows(x2, "layernorm x")
     y = torch.empty((rows, Cc), dtype=torch.float16, device=x.device)
-    _l.check(_l.load().pbe_layernorm_f16(_p(x2), _p(gamma), _p(beta), _p(y), rows, Cc, ldx, Cc, float(eps), _stream()), "pbe_layernorm_f16")
+    with _timed(f"l:{rows}:{Cc}"):
+        _l.check(_l.load().pbe_layernorm_f16(_p(x2), _p(gamma), _p(beta), _p(y), rows, Cc, ldx, Cc, float(eps), _stream()), "pbe_layernorm_f16")
     return y.view(x.shape)
 
 
@@ -239,7 +263,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int
         out = torch.empty((B, Nq, H * D), dtype=torch.float16, device=q.device)
     d = _l.AttnDesc(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, D, q_strides[0], q_strides[1], k_strides[0], k_strides[1],
                     vt_strides[0], vt_strides[1], out.stride(0), out.stride(1), float(scale))
-    _l.check(_l.load().pbe_attention_f16(C.byref(d), _stream()), "pbe_attention_f16")
+    with _timed(f"a:{B}:{H}:{Nq}:{Nk}:{D}"):
+        _l.check(_l.load().pbe_attention_f16(C.byref(d), _stream()), "pbe_attention_f16")
     return out
 
 

@@ -94,11 +94,15 @@ def bench_attn(B=8):
         qk, vt = rnd(B * N, 2 * Cc), rnd(B, Cc, N)
         fl = 4.0 * B * H * N * N * D
         row = f"attn N={N:5d} D={D:3d} x{cnt}:"
-        for qw in (1, 2):
-            ops.tune(3, qw)
-            us = timeit(lambda: ops.attention(qk, qk[:, Cc:], vt, B, H, N, N, D, D ** -0.5, q_strides=(N * 2 * Cc, 2 * Cc), k_strides=(N * 2 * Cc, 2 * Cc),
-                                              vt_strides=(Cc * N, N)))
-            row += f" | qw{qw}: {us:8.1f} us {fl / us / 1e6:7.1f} TF"
+        call = lambda: ops.attention(qk, qk[:, Cc:], vt, B, H, N, N, D, D ** -0.5, q_strides=(N * 2 * Cc, 2 * Cc), k_strides=(N * 2 * Cc, 2 * Cc),
+                                     vt_strides=(Cc * N, N))
+        best = {}
+        for rep in range(3):                        # variants interleaved, best of 3: clocks drift between launches
+            for qw in (1, 2, 3):
+                ops.tune(3, qw)
+                best[qw] = min(best.get(qw, 1e30), timeit(call))
+        for qw in (1, 2, 3):
+            row += f" | qw{qw}: {best[qw]:8.1f} us {fl / best[qw] / 1e6:7.1f} TF"
         ops.tune(3, 0)
         print(row, flush=True)
 
