@@ -169,15 +169,25 @@ def main():
         # ---- separate passes (outside the timed region): stage split and per-kernel-class events ----
         stage = {}
         one_step(timings=stage)
-        prof = None
+        prof, conv_alg_bytes = None, None
         if not a.no_profile:
             ops.prof_reset()
             ops.prof_enable(True)
+            ops._RECORD = {}                                   # shapes of this pass -> algorithmic bytes of the conv launches
             one_step()
             torch.cuda.synchronize()
             ops.prof_enable(False)
             prof = ops.prof_collect()
             ops.prof_reset()
+            shapes, ops._RECORD = ops._RECORD, None
+            nconv = alg = 0
+            for key, cnt in shapes.items():                    # c:B:H:W:C1:C2:Cout:stride:pad:ups — read x once, weights once, write y once (fp16)
+                if key.startswith("c:"):
+                    Bc, H, W, C1, C2, Co, st, pad, ups = (int(v) for v in key.split(":")[1:10])
+                    Ho, Wo = ops.conv_out_hw(H, W, st, pad, bool(ups))
+                    alg += cnt * 2 * (Bc * H * W * (C1 + C2) + Co * 9 * (C1 + C2) + Bc * Ho * Wo * Co)
+                    nconv += cnt
+            conv_alg_bytes = alg / nconv if nconv else None
 
     if rank != 0:
         if world > 1:
@@ -200,9 +210,16 @@ def main():
     }
     if prof:
         conv = prof["conv3x3_igemm"]
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")      # tools/pmc_bench_traffic.py (rocprofv3 --pmc passes over this command)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj.get("traffic_B_per_launch"), "profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         tf = conv["work"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         line["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<*,*,1> (3x3 conv implicit GEMM)", "achieved": tf, "peak": MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "launches": conv["launches"],
+                            "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "B per launch (L2-fabric side)",
+                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_alg_bytes, "launches": conv["launches"],
                             "avg_launch_us": 1e3 * conv["ms"] / max(1, conv["launches"]),
                             "avg_gflop_per_launch": conv["work"] / max(1, conv["launches"]) / 1e9}
         line["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),

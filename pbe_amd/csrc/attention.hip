@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     // re-synchronise at every barrier, so fewer barriers means less time lost to the slowest wave.
     using T = AttnTile<DP>;
     constexpr int KT = T::KT, DV = T::DV, KR = T::KR, VR = T::VR, KSTR = T::KSTR, VSTR = T::VSTR;
-    constexpr int KSLOTS = T::KSLOTS, SLOTS = T::SLOTS, NI = T::NI, NPW = T::NPW, BUF = T::BUF;
+    constexpr int KSLOTS = T::KSLOTS, SLOTS = T::SLOTS, NPW = T::NPW, BUF = T::BUF;
     constexpr int K_BYTES = KSLOTS * 16;
     constexpr int NDS = DP / 16;          // k-steps of the QK^T product
     constexpr int NDT = DV / 32;          // 32-wide d tiles of the output
@@ -179,18 +179,22 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     h16x8 kf[PREF ? 2 : 1][PREF ? NDS : 1];
     h16x8 vf[PREFV ? NDT : 1][4];
     auto load_k = [&](const unsigned char* sk) {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-            kf[0][ds] = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
-            kf[1][ds] = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+            for (int ds = 0; ds < NDS; ++ds) {
+                kf[0][ds] = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
+                kf[1][ds] = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+            }
         }
     };
     auto load_v = [&](const unsigned char* sv) {
+        if constexpr (PREFV) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                vf[dt][ks] = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);
+                for (int ks = 0; ks < 4; ++ks)
+                    vf[dt][ks] = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);
+        }
     };
     auto qk = [&](int i, const unsigned char* sk) {        // S^T = K Q^T : two 32-key sub-tiles
         f32x16& s0 = sc[0];
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            if (PREF) {
+            if constexpr (PREF) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ds], qf[i][ds], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ds], qf[i][ds], s1, 0, 0, 0);
             } else {
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (PREFV) {
+                if constexpr (PREFV) {
                     o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][ks], pf[ks], o[i][dt], 0, 0, 0);
                 } else {
                     const h16x8 v = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);

@@ -36,7 +36,7 @@ int pbe_set_error(int code, const char* fmt, ...);
 // optional per-kernel-class event timing (pbe_prof_*), see profile.cpp
 void pbe_prof_begin(int klass, hipStream_t s);
 void pbe_prof_end(int klass, hipStream_t s, double work);
-enum { PBE_K_CONV3 = 0, PBE_K_GEMM = 1, PBE_K_ATTN = 2, PBE_K_GNORM = 3, PBE_K_LNORM = 4, PBE_K_ELEM = 5, PBE_K_SOFTMAX = 6, PBE_K_COUNT = 7 };
+enum { PBE_K_CONV3 = 0, PBE_K_GEMM = 1, PBE_K_ATTN = 2, PBE_K_GNORM = 3, PBE_K_LNORM = 4, PBE_K_ELEM = 5, PBE_K_SOFTMAX = 6, PBE_K_SPLITK = 7, PBE_K_COUNT = 8 };
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }              // v_rcp_f32, 1 ulp

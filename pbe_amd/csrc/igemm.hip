@@ -50,10 +50,12 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    // S = LDS ring depth (4: three k-tiles in flight, one workgroup per CU for the big tiles; 2: one in flight, the
+    // smaller ring lets 2-4 workgroups share a CU so their prologues / epilogues overlap - shallow-K problems).
     constexpr int NW = NWM * NWN, NT = NW * 64;
-    constexpr int S = 4, D = S - 1;
+    constexpr int D = S - 1;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
     constexpr int PW = BN / 16;                       // 16-row DMA pieces of the weight tile, dealt round-robin to the waves
@@ -366,6 +368,8 @@ static const TileCfg kCfg[] = {
     {128, 128, 2, 2, 2, 0.60}, {128, 64, 2, 2, 2, 0.48}, {64, 128, 2, 2, 2, 0.48}, {64, 64, 2, 2, 2, 0.36},
     {256, 320, 2, 4, 1, 1.04},           // N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
     {128, 320, 2, 4, 1, 0.82}};          // same, half the rows: fills the chip when M / 256 < 256 tiles
+// (Ring depth 2 variants of the 128-row tiles - 2-4 workgroups per CU - were measured for every shape of the path,
+//  profiles/r01_autotune_report.txt round "S2": 20-30 % slower than depth 4 on the shallow-K GEMMs they were meant for.)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index) forces a tile config; -1 = heuristic
@@ -413,24 +417,29 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     return best;
 }
 
-template <int BM, int BN, int NWM, int NWN, int MODE>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
-    constexpr size_t ring = 4 * (BM + BN) * 64;
+    constexpr size_t ring = S * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
+    pbe_prof_begin(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch);
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
+        pbe_prof_begin(PBE_K_SPLITK, s);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, p);
+        pbe_prof_end(PBE_K_SPLITK, s, (double)p.M * p.N * (4.0 * p.splits + 2.0));       // bytes: fp32 slabs in, fp16 out
     }
 }
 
@@ -490,9 +499,7 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
     p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    pbe_prof_begin(PBE_K_GEMM, s);
     dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
-    pbe_prof_end(PBE_K_GEMM, s, 2.0 * d->M * (double)d->N * d->K * d->batch);
     PBE_LAUNCH_CHECK("pbe_gemm_f16");
     return PBE_OK;
 }
@@ -529,9 +536,7 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(p.cb % 32 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "pbe_conv3x3_f16: kblock=%d must be a multiple of 32 dividing C1=%d and C2=%d", p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    pbe_prof_begin(PBE_K_CONV3, s);
     dispatch_igemm<1>(p, 1, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
-    pbe_prof_end(PBE_K_CONV3, s, 2.0 * (double)M * d->Cout * 9.0 * Cin);
     PBE_LAUNCH_CHECK("pbe_conv3x3_f16");
     return PBE_OK;
 }

@@ -29,7 +29,7 @@ std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 volatile int g_on = 0;
 thread_local hipEvent_t t_open = nullptr;
-const char* kNames[PBE_K_COUNT] = {"conv3x3_igemm", "gemm", "attention", "groupnorm", "layernorm", "elementwise", "softmax_rows"};
+const char* kNames[PBE_K_COUNT] = {"conv3x3_igemm", "gemm", "attention", "groupnorm", "layernorm", "elementwise", "softmax_rows", "splitk_reduce"};
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Reduce two rocprofv3 PMC passes over the SAME `bench.py` command to the HBM-side traffic per launch of
+the dominant kernel (the 3x3-conv implicit GEMM, igemm_kernel<..., MODE = 1>), as bench.py's
+`roofline.traffic` wants it.  Counters collected exactly as MI355X_MICROARCH.md §HBM prescribes:
+
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_bench/f -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_bench/w -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
+    python tools/pmc_bench_traffic.py gpurun_out/pmc_bench/f gpurun_out/pmc_bench/w profiles/conv_traffic.json
+
+(separate passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  Units and gfx950 corrections:
+both counters are KiB; FETCH_SIZE tallies 64 B per 128-B request for wide (16 B / lane) coalesced reads —
+every global read of this kernel is a 16 B / lane LDS-DMA or epilogue load — so the read side is doubled;
+WRITE_SIZE is exact for its 16 B / lane stores.  Infinity-Cache hits are counted (the counters sit on the
+L2's fabric side), so this is traffic leaving L2, an upper bound on HBM bytes."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    assert fs, f"no counter_collection.csv under {d}"
+    tot, n = collections.Counter(), collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        tot[name] += float(r["Counter_Value"])
+        key = (name, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            n[name] += 1
+    return tot, n
+
+
+def main(fdir, wdir, outp):
+    ft, fn = per_kernel(fdir, "FETCH_SIZE")
+    wt, wn = per_kernel(wdir, "WRITE_SIZE")
+    conv = [k for k in ft if k.startswith("igemm_kernel<") and k.rstrip().endswith(", 1>")]
+    launches = sum(fn[k] for k in conv)
+    assert launches and launches == sum(wn[k] for k in conv), (launches, sum(wn[k] for k in conv))
+    rd = sum(ft[k] for k in conv) * 1024 * 2
+    wr = sum(wt[k] for k in conv) * 1024
+    rows = {k: {"launches": fn[k], "read_B_per_launch": ft[k] * 2048 / fn[k], "write_B_per_launch": wt[k] * 1024 / max(1, wn[k])} for k in sorted(conv)}
+    out = {"kernel": "igemm_kernel<*,*,*,*,1> (3x3 conv implicit GEMM)", "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile (2 passes of the hot path)",
+           "launches": launches, "read_B_per_launch": rd / launches, "write_B_per_launch": wr / launches, "traffic_B_per_launch": (rd + wr) / launches,
+           "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950: 64 B tallied per 128-B request); WRITE_SIZE KiB x 1024", "per_tile_config": rows}
+    with open(outp, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "per_tile_config"}, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
