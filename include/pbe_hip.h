@@ -76,7 +76,7 @@ typedef struct pbe_gemm_desc {
     int32_t bias_per_row;
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
-    int32_t tile_cfg;       /* -1 = built-in heuristic; 0..8 = block-tile config from a tuning table */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..8) | (split-K factor << 8), factor 0 = library's choice */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 
@@ -106,7 +106,7 @@ typedef struct pbe_conv3x3_desc {
     int32_t act;
     void* workspace;        /* optional split-K scratch, as in pbe_gemm_desc */
     size_t workspace_bytes;
-    int32_t tile_cfg;       /* -1 = heuristic, else tile config index (tuning table) */
+    int32_t tile_cfg;       /* -1 = heuristic, else tile config | (split-K factor << 8), as in pbe_gemm_desc */
     int32_t kblock;         /* channel block cb of Wp's K order: k = ((ci/cb)*9 + tap)*cb + ci%cb; multiple of 32 that
                                divides C1 and C2 (0 = 32).  A pixel's 9 taps are then re-read within 9*cb/32 k-tiles (L2 hits) */
 } pbe_conv3x3_desc;

@@ -372,7 +372,7 @@ static const TileCfg kCfg[] = {
 //  profiles/r01_autotune_report.txt round "S2": 20-30 % slower than depth 4 on the shallow-K GEMMs they were meant for.)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index) forces a tile config; -1 = heuristic
+int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index [| splits << 8]) forces a tile config (and split-K factor); -1 = heuristic
 int g_pbe_allow_splitk = 1;      // pbe_tune(2, 0/1)
 
 static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_bytes, long tiles) {
@@ -394,10 +394,14 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // bytes per FLOP.  pbe_amd/tuned_mi355x.json overrides this per shape (desc.tile_cfg).
 static const double kEffShallow[] = {0.45, 0.70, 0.70, 0.85, 1.00, 0.95, 0.80, 0.45, 0.60};
 
+// want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
+// A requested factor is clamped to what the problem allows (batch 1, >= 8 k-tiles per slice, slabs fit the workspace).
 static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg) {
     Plan best{3, 1};
     double best_score = -1.0;
-    const int forced = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : ((want_cfg >= 0 && want_cfg < kNCfg) ? want_cfg : -1);
+    const int want = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : want_cfg;
+    const int forced = (want >= 0 && (want & 255) < kNCfg) ? (want & 255) : -1;
+    const int want_splits = want >= 0 ? (want >> 8) & 255 : 0;
     const bool shallow = ((p.K + 31) >> 5) < 48;
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
@@ -405,7 +409,16 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
         if (shallow) t.eff = kEffShallow[c];
         const long tm = (p.M + t.bm - 1) / t.bm, tn = (p.N + t.bn - 1) / t.bn;
         const long tiles = tm * tn * batch;
-        const int sp = splits_for(p, t, batch, ws_bytes, tiles);
+        int sp = splits_for(p, t, batch, ws_bytes, tiles);
+        if (forced >= 0 && want_splits > 0) {
+            const int nk = (p.K + 31) >> 5;
+            sp = want_splits;
+            if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) sp = 1;
+            if (sp > nk / 8) sp = nk / 8;
+            while (sp > 1 && (size_t)sp * p.M * p.N * sizeof(float) > ws_bytes) --sp;
+            if (sp < 2) sp = 1;
+            else { const int per = (nk + sp - 1) / sp; sp = (nk + per - 1) / per; }
+        }
         const double useful = (double)p.M * p.N * batch / ((double)tiles * t.bm * t.bn);
         const double blocks = (double)tiles * sp, slots = 256.0 * t.slots_per_cu;
         const double rounds = (double)((long)((blocks + slots - 1) / slots));
@@ -461,7 +474,7 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
 }
 
 extern "C" int pbe_tune(int32_t key, int32_t value) {
-    if (key == 1) { g_pbe_force_cfg = (value >= 0 && value < kNCfg) ? value : -1; return PBE_OK; }
+    if (key == 1) { g_pbe_force_cfg = (value >= 0 && (value & 255) < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);

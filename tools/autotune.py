@@ -7,7 +7,8 @@ product reads at import (pbe_amd/tuned_mi355x.json).  Deterministic at run time:
 1. runs the full pipeline once per batch size with shape recording on (every pbe_gemm_f16 /
    pbe_conv3x3_f16 call of CLIP + VAE + 50 PLMS steps),
 2. times every tile config on synthetic operands of each distinct shape (interleaved, one process),
-3. stores the fastest config index per shape key.
+3. stores the fastest (tile config | split-K factor << 8) per shape key: for the best three tile configs the split-K
+   factor is searched as well (the built-in factor heuristic only knows the grid size).
 """
 import argparse
 import json
@@ -24,6 +25,7 @@ from pbe_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 NCFG = 9
+SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32)
 
 
 def timeit(fn, iters, warm=2):
@@ -95,12 +97,25 @@ def main():
             for cfg in [-1] + list(range(NCFG)):
                 ops.tune(1, cfg)
                 times.append(timeit(call, iters))
+            order = sorted(range(NCFG), key=lambda c: times[c + 1])
+            best, best_t = order[0], times[order[0] + 1]
+            f = key.split(":")
+            nk = (int(f[3]) if f[0] == "g" else 9 * (int(f[4]) + int(f[5]))) // 32
+            split_note = ""
+            if (f[0] == "c" or int(f[4]) == 1) and nk >= 16:                     # split-K exists for batch-1 problems with >= 16 k-tiles
+                for cfg in order[:3]:
+                    for sp in SPLITS:
+                        if sp > nk // 8:
+                            break
+                        ops.tune(1, cfg | (sp << 8))
+                        t = timeit(call, iters)
+                        if t < best_t * 0.985:                                    # a factor must win by > 1.5 % to displace the heuristic's
+                            best, best_t, split_note = cfg | (sp << 8), t, f" split {sp}"
             ops.tune(1, -1)
-            best = min(range(NCFG), key=lambda c: times[c + 1])
             table[key] = best
             tot_h += times[0] * rec[key]
-            tot_b += times[best + 1] * rec[key]
-            lines.append(f"{key:44s} x{rec[key]:4d} heur {times[0]:8.1f} us | best cfg{best} {times[best + 1]:8.1f} us {flops / times[best + 1] / 1e6:7.1f} TF | "
+            tot_b += best_t * rec[key]
+            lines.append(f"{key:44s} x{rec[key]:4d} heur {times[0]:8.1f} us | best cfg{best & 255}{split_note} {best_t:8.1f} us {flops / best_t / 1e6:7.1f} TF | "
                          + " ".join(f"{t:7.1f}" for t in times[1:]))
             print(lines[-1], flush=True)
         lines.append(f"weighted total (per recorded pass): heuristic {tot_h / 1e3:.2f} ms -> tuned {tot_b / 1e3:.2f} ms")
