@@ -20,7 +20,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # per-file extras: keep MFMA results in VGPRs where the VALU consumes them right away (attention softmax),
 # saving ~100 v_accvgpr_read/write per K/V tile
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         # SLP re-pairs the whole accumulator tile into (r0,r2)/(r1,r3) operands for v_pk_fma_f32 (no faster than v_fma_f32 on
+         # gfx950, tools/ubench_valu.hip) above the epilogue: a second 128-160 VGPRs, i.e. scratch spills in the 256-row tiles.
+         "igemm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -24,6 +24,7 @@
 //     weight panel and the activation rows a run touches stay in that XCD's L2.
 //   * epilogue: alpha, bias, row-broadcast vector, activation in fp32 registers -> fp16 C tile in
 //     LDS (one wave-row group at a time) -> whole 16-byte row segments to HBM, residual fused.
+#include <type_traits>
 #include "common.h"
 #include "../../include/pbe_hip.h"
 
@@ -39,6 +40,7 @@ struct IGemmP {
     int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 32)
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
+    int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 0u, 0u};
@@ -98,6 +100,24 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     // tile's BM rows is built once into LDS: tab[tap][row] = pixel index, or -1 outside the (virtual) image.
     int* tab = reinterpret_cast<int*>(smem + S * STAGE);
     unsigned char* dump = smem + S * STAGE + (MODE == 1 ? 9 * BM * 4 : 0);
+    // Epilogue vectors of this tile, staged ONCE at kernel start (their global latency hides under the whole main loop;
+    // fetched inside the epilogue they cost one exposed round trip per 16 output columns - measured 35 % of a K = 320 GEMM):
+    // svec[s][c] = bias[n0 + c] + rowvec[first sample of the tile + s][n0 + c], up to 4 samples per tile.
+    float* svec = reinterpret_cast<float*>(smem + (S * STAGE > WM * CLD * 2 ? S * STAGE : WM * CLD * 2) + (MODE == 1 ? 9 * BM * 4 : 0) +
+                                           ((PW % NW) ? 1024 : 0));
+    const int sv_ns = (p.rowvec && p.group_rows < BM) ? BM / p.group_rows : 1;       // samples per tile (tile is sample-aligned when sv_ok)
+    if (p.sv_ok && p.splits <= 1) {
+        const int s0 = p.rowvec ? m0 / p.group_rows : 0;
+        for (int idx = tid; idx < sv_ns * BN; idx += NT) {
+            const int si = idx / BN, c = idx - si * BN, n = n0 + c;
+            float v = 0.f;
+            if (n < p.N) {
+                if (p.bias && !p.bias_row) v = p.bias[n];
+                if (p.rowvec && (long)(s0 + si) * p.group_rows < p.M) v += (float)p.rowvec[(long)(s0 + si) * p.ldv + n];
+            }
+            svec[si * BN + c] = v;
+        }
+    }
     if (MODE == 1) {
         const int hw = p.Ho * p.Wo, Hv = p.H << p.ups, Wv = p.Wd << p.ups;
         for (int row = tid; row < BM; row += NT) {            // one thread per tile row: one (b, oy, ox) decode, 9 taps
@@ -251,53 +271,76 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     constexpr bool ONE_PASS = (size_t)BM * CLD * 2 <= (size_t)S * STAGE;
     constexpr int NG = ONE_PASS ? 1 : NWM;            // passes
     constexpr int GR = ONE_PASS ? BM : WM;            // rows per pass
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-        __syncthreads();                              // ring reads (g == 0) / previous group's copy-out done
-        if (ONE_PASS || wm == g) {
+    // The register -> LDS half has a compile-time FAST path (bias / row vector staged in svec, one sample per tile, no
+    // per-row bias): the generic form (per-element bounds checks, global bias loads and row-vector gathers with an
+    // integer division per quad, all in one unrolled body) ran ~7 000 instructions per thread and cost 35 % of a
+    // K = 320 GEMM.
+    // Tiles with <= 96 accumulator registers also specialise the activation at compile time (5 copies of the unrolled body);
+    // for the 256-row tiles (128-160 accumulator registers) that many copies push the allocator into scratch, so there the
+    // activation stays a uniform run-time branch per quad.
+    constexpr bool ARMS = TM * TN * 4 <= 96;
+    auto stage = [&](int g, auto FAST, auto ACT) {
+        constexpr bool F = decltype(FAST)::value;
+        const int A = decltype(ACT)::value >= 0 ? decltype(ACT)::value : p.act;
+        // alpha is re-materialised opaquely per pass: as a plain loop invariant, acc * alpha is hoisted out of the pass loop
+        // into a second full set of accumulator registers and the 256-row tiles spill (measured: 30 us of epilogue per tile).
+        float al = p.alpha;
+        asm volatile("" : "+s"(al));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int nl = wn * WN + i * 16 + fq * 4;
-                const int n = n0 + nl;
-                float bn[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && !p.bias_row) {
+        for (int i = 0; i < TN; ++i) {
+            const int nl = wn * WN + i * 16 + fq * 4;
+            const int n = n0 + nl;
+            float bn[4] = {0.f, 0.f, 0.f, 0.f};
+            if (F) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(svec + nl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bn[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) bn[r] = t[r];
+            } else if (!p.sv_ok && p.bias && !p.bias_row) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
+                for (int r = 0; r < 4; ++r) bn[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, bn[r]);
+                if (!F) {
                     const int m = m0 + g * GR + ml;
-                    float v[4];
+                    if (p.sv_ok) {                           // several samples per tile (8x8 level), or a per-row bias
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(svec + (sv_ns > 1 ? (g * GR + ml) / p.group_rows : 0) * BN + nl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bn[r];
-                    if (p.bias && p.bias_row) {
-                        const float bm = (m < p.M) ? p.bias[m] : 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += bm;
-                    }
-                    if (p.rowvec && m < p.M) {
+                        for (int r = 0; r < 4; ++r) v[r] += t[r];
+                    } else if (p.rowvec && m < p.M) {
                         const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (n + r < p.N) v[r] += (float)rv[r];
                     }
-                    if (p.act == PBE_ACT_GEGLU) {            // columns interleaved (x_j, gate_j): out_j = x_j * gelu(gate_j)
-                        h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
-                        *reinterpret_cast<h16x2*>(sC + ml * CLD + (nl >> 1)) = o2;
-                    } else {
-                        apply_act4(v, p.act);
-                        h16x4 o;
+                    if (p.bias && p.bias_row) {
+                        const float bm = (m < p.M) ? p.bias[m] : 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
-                        *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
+                        for (int r = 0; r < 4; ++r) v[r] += bm;
                     }
+                }
+                if (A == PBE_ACT_GEGLU) {                    // columns interleaved (x_j, gate_j): out_j = x_j * gelu(gate_j)
+                    h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
+                    *reinterpret_cast<h16x2*>(sC + ml * CLD + (nl >> 1)) = o2;
+                } else {
+                    apply_act4(v, A);
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+                    *reinterpret_cast<h16x4*>(sC + ml * CLD + nl) = o;
                 }
             }
         }
-        __syncthreads();
-        const bool gg = p.act == PBE_ACT_GEGLU;             // GEGLU halves the output width
-        const int cpr = gg ? CPR / 2 : CPR, Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
+    };
+    // LDS -> global half: whole 16-byte row segments, residual added on the way out
+    auto copy_out = [&](int g, auto GG) {
+        constexpr bool gg = decltype(GG)::value;             // GEGLU halves the output width
+        constexpr int cpr = gg ? CPR / 2 : CPR;
+        const int Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
         for (int idx = tid; idx < GR * cpr; idx += NT) {
             const int row = idx / cpr, ch = idx - row * cpr;
             const int m = m0 + g * GR + row, n = nb + ch * 8;
@@ -321,6 +364,31 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 }
             }
         }
+    };
+    const bool fast = p.sv_ok && sv_ns == 1 && !(p.bias && p.bias_row);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        __syncthreads();                              // ring reads (g == 0) / previous group's copy-out done
+        if (ONE_PASS || wm == g) {
+            auto run = [&](auto FAST) {
+                if constexpr (ARMS) {
+                    switch (p.act) {
+                        case 1: stage(g, FAST, std::integral_constant<int, 1>{}); break;
+                        case 2: stage(g, FAST, std::integral_constant<int, 2>{}); break;
+                        case 3: stage(g, FAST, std::integral_constant<int, 3>{}); break;
+                        case PBE_ACT_GEGLU: stage(g, FAST, std::integral_constant<int, PBE_ACT_GEGLU>{}); break;
+                        default: stage(g, FAST, std::integral_constant<int, 0>{}); break;
+                    }
+                } else {
+                    stage(g, FAST, std::integral_constant<int, -1>{});
+                }
+            };
+            if (fast) run(std::true_type{});
+            else run(std::false_type{});
+        }
+        __syncthreads();
+        if (p.act == PBE_ACT_GEGLU) copy_out(g, std::true_type{});
+        else copy_out(g, std::false_type{});
     }
 }
 
@@ -434,7 +502,9 @@ template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     constexpr size_t ring = S * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0);
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0) +
+                           4 * BN * sizeof(float);                                      // + svec[NSV = 4][BN]
+    p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
