@@ -201,14 +201,23 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         f32x16& s1 = sc[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        if constexpr (PREF) {
 #pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-            if constexpr (PREF) {
+            for (int ds = 0; ds < NDS; ++ds) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][ds], qf[i][ds], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][ds], qf[i][ds], s1, 0, 0, 0);
-            } else {
-                const h16x8 k0 = *reinterpret_cast<const h16x8*>(sk + l31 * KSTR + (ds * 2 + h5) * 16);
-                const h16x8 k1 = *reinterpret_cast<const h16x8*>(sk + (32 + l31) * KSTR + (ds * 2 + h5) * 16);
+            }
+        } else {                                               // large d: fragments read one k-step ahead of their MFMAs
+            const unsigned char* r0 = sk + l31 * KSTR + h5 * 16;
+            const unsigned char* r1 = sk + (32 + l31) * KSTR + h5 * 16;
+            h16x8 a0 = *reinterpret_cast<const h16x8*>(r0), a1 = *reinterpret_cast<const h16x8*>(r1);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                const h16x8 k0 = a0, k1 = a1;
+                if (ds + 1 < NDS) {
+                    a0 = *reinterpret_cast<const h16x8*>(r0 + (ds + 1) * 32);
+                    a1 = *reinterpret_cast<const h16x8*>(r1 + (ds + 1) * 32);
+                }
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[i][ds], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[i][ds], s1, 0, 0, 0);
             }
@@ -265,17 +274,21 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         }
     };
     auto pv = [&](int i, const unsigned char* sv) {        // O^T += V^T P^T
+        if constexpr (PREFV) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if constexpr (PREFV) {
-                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][ks], pf[ks], o[i][dt], 0, 0, 0);
-                } else {
-                    const h16x8 v = *reinterpret_cast<const h16x8*>(sv + (dt * 32 + l31) * VSTR + h5 * 16 + ks * 32);
-                    o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, pf[ks], o[i][dt], 0, 0, 0);
-                }
+                for (int ks = 0; ks < 4; ++ks) o[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][ks], pf[ks], o[i][dt], 0, 0, 0);
+        } else {                                               // large d: fragments read two MFMAs ahead
+            const unsigned char* vb = sv + l31 * VSTR + h5 * 16;
+            h16x8 nx[2] = {*reinterpret_cast<const h16x8*>(vb), *reinterpret_cast<const h16x8*>(vb + 32)};
+#pragma unroll
+            for (int x = 0; x < NDT * 4; ++x) {
+                const h16x8 v = nx[x & 1];
+                if (x + 2 < NDT * 4) nx[x & 1] = *reinterpret_cast<const h16x8*>(vb + ((x + 2) >> 2) * 32 * VSTR + ((x + 2) & 3) * 32);
+                o[i][x >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, pf[x & 3], o[i][x >> 2], 0, 0, 0);
             }
+        }
     };
     // one staged tile: every sub-block's S -> softmax -> PV; `next_k` = K image of the next tile when it is already in LDS
     auto tile = [&](int t, const unsigned char* next_k) {

@@ -39,7 +39,12 @@ def per_kernel(d, counter):
 def main(fdir, wdir, outp):
     ft, fn = per_kernel(fdir, "FETCH_SIZE")
     wt, wn = per_kernel(wdir, "WRITE_SIZE")
-    conv = [k for k in ft if k.startswith("igemm_kernel<") and k.rstrip().endswith(", 1>")]
+    def is_conv(k):                                   # igemm_kernel<BM, BN, NWM, NWN, MODE, S>: MODE 1 = 3x3 conv
+        if not k.startswith("igemm_kernel<"):
+            return False
+        args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        return len(args) >= 5 and args[4] == "1"
+    conv = [k for k in ft if is_conv(k)]
     launches = sum(fn[k] for k in conv)
     assert launches and launches == sum(wn[k] for k in conv), (launches, sum(wn[k] for k in conv))
     rd = sum(ft[k] for k in conv) * 1024 * 2
