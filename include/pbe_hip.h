@@ -82,14 +82,14 @@ int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pbe_conv3x3_f16 — NHWC 3x3 convolution as an implicit GEMM on the matrix cores.
- *   Y[b,oy,ox,co] = act(sum_{dy,dx,ci} X[b, iy, ix, ci] * Wp[co, (dy*3+dx)*Cin + ci] + bias[co]
- *                       + rowvec[b, co]) + R[b,oy,ox,co]
+ *   Y[b,oy,ox,co] = act(sum_{dy,dx,ci} X[b, iy, ix, ci] * Wp[co, k(dy*3+dx, ci)] + bias[co]
+ *                       + rowvec[b, co]) + R[b,oy,ox,co]        (k(tap, ci): see kblock below)
  *   iy = oy*stride + dy - pad (zero outside), optional nearest-2x upsample of X fused in the gather,
  *   X optionally the channel concat of two tensors (X | X2).
  * Replaces Conv2d(k=3) dispatches in openaimodel.py:216,229-231 (ResBlock), :109-119 (Upsample:
  * F.interpolate + conv), :150-160 (Downsample s2 p1), :658-662,824-828 (conv in/out);
  * model.py:44-81,92-121 (VAE convs; Downsample pad (0,1,0,1) + s2 p0 == pad=0 here).
- * Requires (C1+C2) % 64 == 0 and C1 % 64 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
+ * Requires C1 % 32 == 0 and C2 % 32 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
  * Wp is the OIHW weight re-packed by the host to [Cout, 9*Cin] in (channel block, tap, channel) order — see kblock.
  * ------------------------------------------------------------------------------------------ */
 typedef struct pbe_conv3x3_desc {
