@@ -201,7 +201,8 @@ def main():
         "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batch=4/GPU, 512x512, 50 PLMS steps (51 U-Net calls at batch 8), scale=5, fp16 "
-                               "activations + fp32 accumulate, name-seeded random-init U-Net + VAE + CLIP ViT-L/14 weights",
+                               "activations + fp32 accumulate, name-seeded random-init U-Net + VAE + CLIP ViT-L/14 weights; the "
+                               "context-independent prefix of each guidance pair (first ResBlock + first self-attention) is evaluated once",
                    "per_gpu_batch": B, "global_batch": world * B, "plms_steps": a.plms_steps, "cfg_scale": a.scale,
                    "parallelism": f"batch-sharded x{world}, no per-step collective"},
         "unet_ms_per_step_per_image": stage.get("sampler_ms", 0.0) / a.plms_steps / B,

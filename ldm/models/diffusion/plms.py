@@ -44,6 +44,7 @@ class PLMSSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
+        self.share_guidance_prefix = True   # evaluate the context-independent prefix of a guidance pair once (UNetModel.forward_nhwc paired=True)
         self.require_gpu = True       # host-logic tests clear this and substitute the two element-wise kernels; the kernels themselves have no CPU path
 
     def register_buffer(self, name, attr):
@@ -84,9 +85,12 @@ class PLMSSampler(object):
     # ---- one U-Net evaluation with guidance (plms.py:181-195) -----------------------------------
     def _eps(self, x, step, ctx, z_inp, msk, dup):
         b = x.shape[0]
-        x9 = ops.plms_pack_input(x, z_inp, msk, dup)
         t = torch.full((dup * b,), int(step), device=x.device, dtype=torch.int64)
-        return self.model.model.diffusion_model.forward_nhwc(x9, t, ctx)
+        unet = self.model.model.diffusion_model
+        if dup == 2 and self.share_guidance_prefix:
+            # cat([x]*2), cat([t]*2) (plms.py:183-184): both halves share x and t; the U-Net evaluates the common prefix once
+            return unet.forward_nhwc(ops.plms_pack_input(x, z_inp, msk, 1), t, ctx, paired=True)
+        return unet.forward_nhwc(ops.plms_pack_input(x, z_inp, msk, dup), t, ctx)
 
     def _coef(self, index, weights):
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])

@@ -255,17 +255,37 @@ class UNetModel(HipModule):
                 h = layer.run(h)
         return h
 
-    def forward_nhwc(self, x16, timesteps, context):
-        """x16 [B,H,W,cin_pad] fp16 (channels >= in_channels zero) -> eps [B,H,W,out_channels] fp16."""
+    def forward_nhwc(self, x16, timesteps, context, paired=False):
+        """x16 [B,H,W,cin_pad] fp16 (channels >= in_channels zero) -> eps [B,H,W,out_channels] fp16.
+
+        paired=True is the classifier-free-guidance call of the samplers (plms.py:182-189): the reference feeds
+        cat([x]*2), cat([t]*2), cat([uc, c]) - both halves share x and t and differ ONLY in the context.  Then x16 holds the
+        B shared inputs while timesteps / context hold 2B rows, and everything upstream of the first context-dependent
+        operation (conv_in, the first ResBlock, the first transformer's GroupNorm / proj_in / LayerNorm / q,k,v /
+        attention core) is computed once and serves both halves.  Exact common-subexpression elimination: every kernel
+        is deterministic and per-sample, so the duplicated evaluation would reproduce the same bits."""
         p = self.pk()
         ctx = self.context_vectors(context)
         t_emb = timestep_embedding(timesteps, self.model_channels)
         e = ops.gemm(t_emb, p.te0_w, p.te0_b, act=ops.ACT_SILU)
         e = ops.gemm(e, p.te2_w, p.te2_b, act=ops.ACT_SILU)          # SiLU(emb): emb is only ever consumed through SiLU
         emb_all = ops.gemm(e, p.emb_w, p.emb_b)                        # all 22 emb_layers at once
-        h = ops.conv3x3_small(x16, p.w_in, p.b_in)
-        hs = [h]
-        for block in list(self.input_blocks)[1:]:
+        blocks = list(self.input_blocks)[1:]
+        if paired:
+            B = x16.shape[0]
+            first = list(blocks[0])
+            if timesteps.shape[0] != 2 * B or len(first) != 2 or not isinstance(first[0], ResBlock) or not isinstance(first[1], SpatialTransformer):
+                raise PbeError("UNetModel.forward_nhwc(paired=True): needs 2B timesteps and a [ResBlock, SpatialTransformer] first block")
+            h0 = ops.conv3x3_small(x16, p.w_in, p.b_in)
+            off, n = p.emb_off[id(first[0])]
+            r = first[0].run(h0, emb_all[:B, off:off + n])
+            h = first[1].run_paired(r, ctx[id(first[1])])
+            hs = [torch.cat([h0, h0], 0), h]
+            blocks = blocks[1:]
+        else:
+            h = ops.conv3x3_small(x16, p.w_in, p.b_in)
+            hs = [h]
+        for block in blocks:
             h = self._run_block(block, h, emb_all, p, ctx)
             hs.append(h)
         h = self._run_block(self.middle_block, h, emb_all, p, ctx)

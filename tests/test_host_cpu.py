@@ -99,8 +99,11 @@ class _FakeUNet:
     def __init__(self, sd):
         self.sd, self.calls, self.batches = sd, 0, []
 
-    def forward_nhwc(self, x9, t, ctx):
+    def forward_nhwc(self, x9, t, ctx, paired=False):
         self.calls += 1
+        if paired:                                   # shared-prefix guidance call: B inputs, 2B timesteps / contexts
+            assert x9.shape[0] * 2 == t.shape[0] == ctx.shape[0]
+            x9 = torch.cat([x9, x9])
         self.batches.append(int(x9.shape[0]))
         x = x9.float()[..., :9].permute(0, 3, 1, 2)
         y = O.unet_forward(self.sd, x, t, ctx.float(), cases.UNET_NARROW, "model.diffusion_model.")

@@ -241,6 +241,27 @@ def test_full_pipeline_is_batch_independent(dev, full):
     assert torch.equal(both["latent"], again["latent"]) and torch.equal(both["image"], again["image"])       # run-to-run bit-identical
 
 
+def test_full_unet_shared_guidance_prefix(dev, full):
+    """forward_nhwc(paired=True) (the context-independent prefix of a guidance pair evaluated once) against the plain
+    duplicated batch: same function; the prefix runs at batch B instead of 2B, so tile configs / split-K factors and with
+    them the fp32 summation order may differ -> two fp16 evaluations of the same math, bound 2e-3 like batch independence."""
+    from pbe_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    x = torch.randn(B, 4, 64, 64, generator=g).to(dev)
+    z = torch.randn(B, 4, 64, 64, generator=g).to(dev)
+    m = (torch.rand(B, 1, 64, 64, generator=g) > 0.3).float().to(dev)
+    ctx = torch.randn(2 * B, 1, 768, generator=g).to(dev)
+    t = torch.full((2 * B,), 621, dtype=torch.int64, device=dev)
+    unet = full.model.diffusion_model
+    with torch.no_grad():
+        a = unet.forward_nhwc(ops.plms_pack_input(x, z, m, 2), t, ctx)
+        b = unet.forward_nhwc(ops.plms_pack_input(x, z, m, 1), t, ctx, paired=True)
+    assert a.shape == b.shape == (2 * B, 64, 64, 4)
+    check("guidance pair: shared prefix vs duplicated batch", b, a.float().cpu(), 2e-3)
+    assert not torch.equal(b[:B], b[B:])                      # the halves really differ (different contexts)
+
+
 def test_full_unet_768_latents_and_batch32(dev, full):
     """BASELINE configs[4] geometry (768x768 pixels -> 96x96 latents, 9216-token self-attention) and configs[2]'s U-Net batch
     (16 images under CFG = 32): the kernels accept the sizes, outputs are finite, deterministic, and sample-independent."""
