@@ -366,3 +366,49 @@ def test_groupnorm_small_map_single_launch(dev, B, HW, C):
     _close(ops.groupnorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True), ref, rtol=3e-3, what=f"groupnorm small C={C} HW={HW}")
     x1, x2 = x[..., :C // 2].contiguous(), x[..., C // 2:].contiguous()
     _close(ops.groupnorm(x1.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True, x2=x2.to(dev)), ref, rtol=3e-3, what="groupnorm small concat")
+
+
+@pytest.mark.parametrize("cfg", list(range(9)) + [0 | (3 << 8), 4 | (2 << 8)])
+def test_every_tile_config_with_every_epilogue(dev, cfg):
+    """Each block-tile config (and two forced split-K factors) through the epilogue variants that have their own code path:
+    bias + per-sample row vector staged in LDS with 1, 2 and 4 samples per tile (8x8 level: 64 pixels per sample), the
+    unaligned fall-back (row groups that do not tile), SiLU / GEGLU, residual, per-row bias; M and N off the tile grid."""
+    from pbe_amd import ops
+    g = _g(77 + (cfg & 255))
+    ops.tune(1, cfg)
+    try:
+        # conv, 8 samples of 8x8 (M = 512): a 256-row tile spans 4 samples, a 128-row tile 2, a 64-row tile 1
+        B, H, W, Ci, Co = 8, 8, 8, 64, 200
+        x = torch.randn(B, H, W, Ci, generator=g).half()
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).half()
+        b = torch.randn(Co, generator=g)
+        emb = torch.randn(B, Co, generator=g).half()
+        res = torch.randn(B, H, W, Co, generator=g).half()
+        ref = F.silu((_conv_ref(x, w, b, 1, 1, False) + emb.float()[:, None, None, :])).half().float() + res.float()
+        got = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w.float()).to(dev), b.to(dev), rowvec=emb.to(dev), resid=res.to(dev), act=ops.ACT_SILU)
+        _close(got, ref, what=f"cfg {cfg}: conv 8x8x8 emb+silu+resid")
+        # GEMM with row groups of 48 rows (do not tile 64/128/256): generic path
+        M, N, K, grp = 336, 328, 192, 48
+        a = torch.randn(M, K, generator=g).half()
+        wl = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+        bias = torch.randn(N, generator=g)
+        rv = torch.randn(M // grp, N, generator=g).half()
+        ref = (a.float() @ wl.float().t() + bias + rv.float().repeat_interleave(grp, 0)).half().float()
+        got = ops.gemm(a.to(dev), wl.to(dev), bias.to(dev), rowvec=rv.to(dev), group_rows=grp)
+        _close(got, ref, what=f"cfg {cfg}: gemm rowvec groups of 48")
+        # per-row bias (the V^T projection's orientation) and alpha
+        bm = torch.randn(M, generator=g)
+        ref = (0.5 * (a.float() @ wl.float().t()) + bm[:, None]).half().float()
+        got = ops.gemm(a.to(dev), wl.to(dev), bm.to(dev), bias_per_row=True, alpha=0.5)
+        _close(got, ref, what=f"cfg {cfg}: gemm per-row bias, alpha")
+        # fused GEGLU (value / gate rows interleaved by pack_geglu), rows off the tile grid
+        Fo = 160
+        w2 = (torch.randn(2 * Fo, K, generator=g) / math.sqrt(K)).half()
+        b2 = torch.randn(2 * Fo, generator=g)
+        h = a.float() @ w2.float().t() + b2
+        ref = (h[:, :Fo] * F.gelu(h[:, Fo:])).half().float()
+        wi, bi = ops.pack_geglu(w2.float(), b2)
+        got = ops.gemm(a.to(dev), wi.to(dev), bi.to(dev), act=ops.ACT_GEGLU)
+        _close(got, ref, what=f"cfg {cfg}: fused GEGLU")
+    finally:
+        ops.tune(1, -1)
