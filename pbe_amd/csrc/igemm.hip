@@ -398,20 +398,35 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
     const int n4 = p.N >> 2;
     if (i >= (long)p.M * n4) return;
     const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.splits; ++z) a += *reinterpret_cast<const f32x4*>(p.ws + ((long)z * p.M + m) * p.N + n);
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+    // every global load of this thread is issued up front (epilogue operands, then the slabs four at a time): with one
+    // load per loop trip the kernel is a chain of `splits` memory round trips.  The ADD order stays slab 0, 1, 2, ... (deterministic).
+    float ev[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.bias_row ? p.bias[m] : p.bias[n + r];
+        for (int r = 0; r < 4; ++r) ev[r] = p.bias_row ? p.bias[m] : p.bias[n + r];
     }
     if (p.rowvec) {
         const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        for (int r = 0; r < 4; ++r) ev[r] += (float)rv[r];
     }
+    if (p.resid && p.act != PBE_ACT_GEGLU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[r] = (float)p.resid[(long)m * p.ldr + n + r];
+    }
+    const float* sl = p.ws + (long)m * p.N + n;
+    const long zs = (long)p.M * p.N;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= p.splits; z += 4) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(sl + (z + 0) * zs), t1 = *reinterpret_cast<const f32x4*>(sl + (z + 1) * zs);
+        const f32x4 t2 = *reinterpret_cast<const f32x4*>(sl + (z + 2) * zs), t3 = *reinterpret_cast<const f32x4*>(sl + (z + 3) * zs);
+        a += t0; a += t1; a += t2; a += t3;
+    }
+    for (; z < p.splits; ++z) a += *reinterpret_cast<const f32x4*>(sl + z * zs);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha + ev[r];
     if (p.act == PBE_ACT_GEGLU) {
         h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
         *reinterpret_cast<h16x2*>(p.C + (long)m * p.ldc + (n >> 1)) = o2;
@@ -420,8 +435,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
     h16x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float f = (float)(h16)apply_act(v[r], p.act);          // same rounding point as the fused epilogue
-        if (p.resid) f += (float)p.resid[(long)m * p.ldr + n + r];
+        const float f = (float)(h16)apply_act(v[r], p.act) + rs[r];          // same rounding point as the fused epilogue
         o[r] = (h16)f;
     }
     *reinterpret_cast<h16x4*>(p.C + (long)m * p.ldc + n) = o;
