@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--batches", default="1,4,8")
     ap.add_argument("--out", default=os.path.join(ROOT, "pbe_amd", "tuned_mi355x.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "autotune_report.txt"))
+    ap.add_argument("--merge", default="", help="existing table: its keys are kept as they are, only new shapes are measured")
     a = ap.parse_args()
     import cases
     import modelbuild
@@ -89,6 +90,11 @@ def main():
         del model
         torch.cuda.empty_cache()
         table, lines = {}, []
+        if a.merge:
+            with open(a.merge) as f:
+                table = json.load(f)
+            rec = {k: v for k, v in rec.items() if k not in table}
+            print(f"[autotune] {len(table)} shapes kept from {a.merge}, {len(rec)} new", flush=True)
         tot_h = tot_b = 0.0
         for key in sorted(rec):
             call, flops = make_call(key)
