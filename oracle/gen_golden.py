@@ -423,6 +423,33 @@ def gen_full():
     save("full", **out)
 
 
+def gen_full_plms():
+    """Full-size (configs/v1.yaml) PLMS trajectory with the REFERENCE sampler and U-Net: 4 steps, guidance 5, one sample."""
+    UP = "model.diffusion_model."
+    inp = CASES.full_plms_inputs()
+    unet = build_ref_unet(O.UNET_V1, UP)
+    sd = sd_of(unet, UP)
+    lm = _RefLatentModel(unet)
+    kw = {"images_inpaint": inp["z_inpaint"], "images_mask": inp["mask_lat"]}
+    t0 = time.time()
+    z0, inter = _CpuPLMS(lm).sample(S=inp["steps"], batch_size=1, shape=[4, 64, 64], conditioning=inp["c"], verbose=False,
+                                    unconditional_guidance_scale=inp["scale"], unconditional_conditioning=inp["uc"], eta=0.0,
+                                    x_T=inp["x_T"].clone(), log_every_t=1, test_model_kwargs=kw)
+    print(f"  reference full-size PLMS {inp['steps']} steps: {time.time() - t0:.1f}s, apply_model calls = {lm.calls}")
+    assert lm.calls == inp["steps"] + 1
+    xs = inter["x_inter"]
+    oz, info = O.plms_sample(lambda a, b, cc_: O.unet_forward(sd, a, b, cc_, O.UNET_V1, UP), inp["steps"], inp["x_T"], inp["c"], inp["uc"],
+                             inp["scale"], inp["z_inpaint"], inp["mask_lat"], O.schedule_buffers()["alphas_cumprod"],
+                             record=tuple(range(inp["steps"])))
+    out = {}
+    for i in range(inp["steps"]):
+        close(info["x"][i], xs[i + 1], f"full-size PLMS x after step {i}", rtol=2e-3)
+        out[f"plms_x_{i}"] = xs[i + 1]
+    close(oz, z0, "full-size PLMS final latent", rtol=2e-3)
+    out["plms_latent"] = z0
+    save("full_plms", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -439,3 +466,5 @@ if __name__ == "__main__":
         gen_full_manifest()
     if "full" in todo:
         gen_full()
+    if "full_plms" in todo:
+        gen_full_plms()

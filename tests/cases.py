@@ -70,3 +70,12 @@ def full_inputs():
          "z_dec": torch.randn(1, 4, 64, 64, generator=g) * 0.18215 * 4.0,
          "ref": torch.randn(1, 3, 224, 224, generator=g)}
     return d
+
+
+def full_plms_inputs():
+    """Inputs of tests/golden/full_plms.npz: ONE sample at configs/v1.yaml size, 4 PLMS steps (5 U-Net calls under guidance)."""
+    g = torch.Generator().manual_seed(777)
+    m = torch.ones(1, 1, 64, 64)
+    m[:, :, 20:44, 12:40] = 0.0
+    return {"x_T": torch.randn(1, 4, 64, 64, generator=g), "z_inpaint": torch.randn(1, 4, 64, 64, generator=g) * 0.8, "mask_lat": m,
+            "c": torch.randn(1, 1, 768, generator=g), "uc": torch.randn(1, 1, 768, generator=g), "steps": 4, "scale": 5.0}

@@ -241,6 +241,23 @@ def test_full_pipeline_is_batch_independent(dev, full):
     assert torch.equal(both["latent"], again["latent"]) and torch.equal(both["image"], again["image"])       # run-to-run bit-identical
 
 
+def test_full_plms_trajectory_against_reference(dev, golden_dir, full):
+    """configs/v1.yaml-size PLMS under guidance against the REFERENCE sampler + UNetModel (tests/golden/full_plms.npz,
+    oracle/gen_golden.py --only full_plms): 4 steps = 5 U-Net calls on one sample, every intermediate x."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = np.load(os.path.join(golden_dir, "full_plms.npz"))
+    inp = cases.full_plms_inputs()
+    with torch.no_grad():
+        z0, inter = PLMSSampler(full).sample(S=inp["steps"], batch_size=1, shape=[4, 64, 64], conditioning=inp["c"].to(dev), verbose=False,
+                                             unconditional_guidance_scale=inp["scale"], unconditional_conditioning=inp["uc"].to(dev), eta=0.0,
+                                             x_T=inp["x_T"].to(dev), log_every_t=1,
+                                             test_model_kwargs={"images_inpaint": inp["z_inpaint"].to(dev), "images_mask": inp["mask_lat"].to(dev)})
+    assert len(inter["x_inter"]) == inp["steps"] + 1
+    for i, tol in zip(range(inp["steps"]), (4e-3, 6e-3, 8e-3, 1e-2)):
+        check(f"v1-size PLMS x after step {i}", inter["x_inter"][i + 1], g[f"plms_x_{i}"], tol)
+    check("v1-size PLMS final latent (4 steps)", z0, g["plms_latent"], 1e-2)
+
+
 def test_full_unet_shared_guidance_prefix(dev, full):
     """forward_nhwc(paired=True) (the context-independent prefix of a guidance pair evaluated once) against the plain
     duplicated batch: same function; the prefix runs at batch B instead of 2B, so tile configs / split-K factors and with
