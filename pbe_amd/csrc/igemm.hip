@@ -446,10 +446,10 @@ struct Plan { int cfg; int splits; };
 struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
 // eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP)
 static const TileCfg kCfg[] = {
-    {256, 256, 2, 4, 1, 1.00}, {256, 128, 4, 2, 1, 0.80}, {128, 256, 2, 4, 1, 0.80},
-    {128, 128, 2, 2, 2, 0.60}, {128, 64, 2, 2, 2, 0.48}, {64, 128, 2, 2, 2, 0.48}, {64, 64, 2, 2, 2, 0.36},
-    {256, 320, 2, 4, 1, 1.04},           // N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
-    {128, 320, 2, 4, 1, 0.82}};          // same, half the rows: fills the chip when M / 256 < 256 tiles
+    {256, 256, 2, 4, 1, 1.00}, {256, 128, 4, 2, 1, 0.82}, {128, 256, 2, 4, 1, 0.75},
+    {128, 128, 2, 2, 2, 0.88}, {128, 64, 2, 2, 2, 0.65}, {64, 128, 2, 2, 2, 0.65}, {64, 64, 2, 2, 2, 0.60},
+    {256, 320, 2, 4, 1, 1.05},           // N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
+    {128, 320, 2, 4, 1, 0.96}};          // same, half the rows: fills the chip when M / 256 < 256 tiles
 // (Ring depth 2 variants of the 128-row tiles - 2-4 workgroups per CU - were measured for every shape of the path,
 //  profiles/r01_autotune_report.txt round "S2": 20-30 % slower than depth 4 on the shallow-K GEMMs they were meant for.)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
@@ -471,10 +471,11 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
     return (nk + per - 1) / per;                      // no empty slice
 }
 
-// Shallow-K problems are dominated by the prologue / epilogue and by HBM traffic, where many small
-// workgroups beat few large ones (measured, tools/bench_kernels.py); deep-K problems by staged
-// bytes per FLOP.  pbe_amd/tuned_mi355x.json overrides this per shape (desc.tile_cfg).
-static const double kEffShallow[] = {0.45, 0.70, 0.70, 0.85, 1.00, 0.95, 0.80, 0.45, 0.60};
+// Shallow-K problems (< 20 k-tiles) are dominated by the prologue / epilogue, deep-K problems by staged bytes per
+// FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report*.txt (the
+// heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
+// this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95};
 
 // want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
 // A requested factor is clamped to what the problem allows (batch 1, >= 8 k-tiles per slice, slabs fit the workspace).
@@ -484,7 +485,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     const int want = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : want_cfg;
     const int forced = (want >= 0 && (want & 255) < kNCfg) ? (want & 255) : -1;
     const int want_splits = want >= 0 ? (want >> 8) & 255 : 0;
-    const bool shallow = ((p.K + 31) >> 5) < 48;
+    const bool shallow = ((p.K + 31) >> 5) < 20;
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];

@@ -49,6 +49,8 @@ import os as _os
 
 _TUNED_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned_mi355x.json")
 try:
+    if _os.environ.get("PBE_NO_TUNED"):          # evaluate the built-in heuristic (tools / tests only)
+        raise OSError("tuned table disabled by PBE_NO_TUNED")
     with open(_TUNED_PATH) as _tuned_file:
         _TUNED = _json.load(_tuned_file)
 except (OSError, ValueError):
