@@ -472,7 +472,7 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 }
 
 // Shallow-K problems (< 20 k-tiles) are dominated by the prologue / epilogue, deep-K problems by staged bytes per
-// FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report*.txt (the
+// FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
 static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95};

@@ -111,7 +111,7 @@ def main():
             nk = (int(f[3]) if f[0] == "g" else 9 * (int(f[4]) + int(f[5]))) // 32
             split_note = ""
             if (f[0] == "c" or int(f[4]) == 1) and nk >= 16:                     # split-K exists for batch-1 problems with >= 16 k-tiles
-                for cfg in order[:3]:
+                for cfg in order[:6]:
                     for sp in SPLITS:
                         if sp > nk // 8:
                             break
