@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from pbe_amd import ops
+from pbe_amd.graph import GraphedUNet, graphs_enabled
 from pbe_amd.lib import PbeError
 from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
 
@@ -44,6 +45,8 @@ class PLMSSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
+        self.use_graph = None               # None = decide per run (pbe_amd.graph.graphs_enabled); True / False force
+        self._graphed = None
         self.share_guidance_prefix = True   # evaluate the context-independent prefix of a guidance pair once (UNetModel.forward_nhwc paired=True)
         self.require_gpu = True       # host-logic tests clear this and substitute the two element-wise kernels; the kernels themselves have no CPU path
 
@@ -87,10 +90,14 @@ class PLMSSampler(object):
         b = x.shape[0]
         t = torch.full((dup * b,), int(step), device=x.device, dtype=torch.int64)
         unet = self.model.model.diffusion_model
-        if dup == 2 and self.share_guidance_prefix:
-            # cat([x]*2), cat([t]*2) (plms.py:183-184): both halves share x and t; the U-Net evaluates the common prefix once
-            return unet.forward_nhwc(ops.plms_pack_input(x, z_inp, msk, 1), t, ctx, paired=True)
-        return unet.forward_nhwc(ops.plms_pack_input(x, z_inp, msk, dup), t, ctx)
+        # cat([x]*2), cat([t]*2) (plms.py:183-184): both halves share x and t; the U-Net evaluates the common prefix once
+        paired = dup == 2 and self.share_guidance_prefix
+        x9 = ops.plms_pack_input(x, z_inp, msk, 1 if paired else dup)
+        if (graphs_enabled(dup * b) if self.use_graph is None else self.use_graph) and x.is_cuda:      # launch-bound regime: one HIP graph per call
+            if self._graphed is None or self._graphed.unet is not unet:
+                self._graphed = GraphedUNet(unet)
+            return self._graphed(x9, t, ctx, paired)
+        return unet.forward_nhwc(x9, t, ctx, paired=paired)
 
     def _coef(self, index, weights):
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])

@@ -151,12 +151,15 @@ def _sample(narrow, dev, g, sampler_cls, S, spelling):
         return orig(*a, **k)
 
     unet.forward_nhwc = counting
+    smp = sampler_cls(narrow)
     try:
-        out, inter = sampler_cls(narrow).sample(S=S, batch_size=2, shape=[4, 16, 16], conditioning=c, verbose=False, unconditional_guidance_scale=5.0,
-                                                unconditional_conditioning=uc, eta=0.0, x_T=inp["x_T"].to(dev), log_every_t=1, test_model_kwargs=kw)
+        out, inter = smp.sample(S=S, batch_size=2, shape=[4, 16, 16], conditioning=c, verbose=False, unconditional_guidance_scale=5.0,
+                                unconditional_conditioning=uc, eta=0.0, x_T=inp["x_T"].to(dev), log_every_t=1, test_model_kwargs=kw)
     finally:
         unet.forward_nhwc = orig
-    return out, inter, calls["n"]
+    # U-Net evaluations = Python-level calls, or (HIP-graph regime) one eager call + replays; the capture pass is not an evaluation
+    n = calls["n"] if smp._graphed is None else 1 + smp._graphed.replays
+    return out, inter, n
 
 
 def test_narrow_plms_trajectory(dev, gold, narrow):
@@ -186,6 +189,29 @@ def test_narrow_plms_key_spelling_and_ddim(dev, gold, narrow):
     assert torch.equal(a, b)
     assert n == 20
     check("DDIM 20-step latent", zd, g["ddim_latent"], 3e-2)
+
+
+def test_hip_graph_replay_is_bit_identical(dev, gold, narrow):
+    """pbe_amd.graph: the U-Net call captured once into a HIP graph and replayed (launch-bound regime) produces the same
+    bits as eager launches over a 10-step PLMS run, and really replays (10 of the 11 calls)."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = gold["narrow"]
+    outs = {}
+    with torch.no_grad():
+        for use in (False, True):
+            smp = PLMSSampler(narrow)
+            smp.use_graph = use
+            inp = cases.narrow_inputs()
+            z0, _ = smp.sample(S=10, batch_size=2, shape=[4, 16, 16], conditioning=torch.from_numpy(g["c"]).to(dev), verbose=False,
+                               unconditional_guidance_scale=5.0, unconditional_conditioning=narrow.learnable_vector, eta=0.0,
+                               x_T=inp["x_T"].to(dev), test_model_kwargs={"inpaint_image": torch.from_numpy(g["z_inpaint"]).to(dev),
+                                                                          "inpaint_mask": torch.from_numpy(g["mask_lat"]).to(dev)})
+            outs[use] = z0.clone()
+            if use:
+                assert smp._graphed is not None and smp._graphed.replays == 10
+            else:
+                assert smp._graphed is None
+    assert torch.equal(outs[False], outs[True])
 
 
 # ---- full-size (configs/v1.yaml) single forwards -------------------------------------------------
