@@ -23,12 +23,68 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE config #2: 4)")
+    ap.add_argument("--plms-steps", type=int, default=50)
+    ap.add_argument("--scale", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="tests only: workers rendezvous (gloo), all-reduce one number and rank 0 prints a JSON line; no GPU work")
+    return ap.parse_args(argv)
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: this process becomes a pure launcher.
+    It starts N workers (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE importing torch or touching
+    HIP in any way, waits for them, and returns non-zero if any worker failed.  Rank 0 inherits stdout, so its single
+    JSON line is the launcher's output; the other ranks' stdout goes to stderr.  Nothing is exec'ed: the workers are
+    child processes, and a failed worker takes the rest down (exact PIDs) instead of leaving them in a rendezvous."""
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(a.gpus))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(alive):
+                    procs[o].terminate()
+        if alive:
+            time.sleep(0.2)
+    return rc
+
+
+if __name__ == "__main__" and "RANK" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(self_launch(_a))
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -103,24 +159,30 @@ def cpu_baseline(cpu_sd, threads):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE config #2: 4)")
-    ap.add_argument("--plms-steps", type=int, default=50)
-    ap.add_argument("--scale", type=float, default=5.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    a = ap.parse_args()
+    a = parse_args()
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:          # checked before anything touches the GPU
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; run `python bench.py --gpus N` (self-launching) "
+                         "or torch.distributed.run with --nproc-per-node equal to --gpus")
+    if os.environ.get("PBE_BENCH_FAIL_RANK") == str(rank):          # tests only: a worker that dies before the rendezvous
+        raise SystemExit(3)
+    backend = os.environ.get("PBE_DIST_BACKEND", "nccl")
+    if a.rehearse_launch:        # tests only (tests/test_shard_gloo.py): the launch / rendezvous / relay path without a GPU
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": a.steps, "warmup": a.warmup}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # one process per GPU.  PBE_DIST_BACKEND=gloo + fewer GPUs than ranks is a REHEARSAL mode only
     # (ranks share a card): it exercises the sharding / broadcast / gather code on a 1-GPU box.
-    backend = os.environ.get("PBE_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     dev_index = local if (backend == "nccl" or local < ndev) else local % ndev
     torch.cuda.set_device(dev_index)
@@ -130,7 +192,6 @@ def main():
             dist.init_process_group("nccl", device_id=device)          # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
 
     import cases
     from pbe_amd import ops

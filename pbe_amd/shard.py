@@ -4,8 +4,8 @@ Every image triple is independent (GroupNorm and attention are per-sample, a CFG
 one GPU), so the path shards with NO per-step collective.  One process per GPU
 (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" for the CPU tests):
 
-  * ``shard_indices``      rank r of W takes samples r::W of a work list (drop_last like the
-                           reference's test bench, scripts/inference_test_bench.py:301),
+  * the work partition itself is ``pbe_amd.testbench.rank_batches`` (whole batches dealt round-robin, drop_last like the
+    reference's test bench, scripts/inference_test_bench.py:301); ``bench.py`` gives every rank its own B synthetic triples,
   * ``broadcast_weights_`` ONE-OFF broadcast of the weights from rank 0 in a few large contiguous
                            buffers (xGMI is point-to-point: a broadcast is per-link bound, so few big
                            messages, not 1 400 small ones),
@@ -19,24 +19,6 @@ import torch
 import torch.distributed as dist
 
 BUCKET_BYTES = 1 << 30          # 1 GiB buckets: 2.6-5.2 GB of weights -> 3-6 broadcasts
-
-
-def shard_indices(n_items: int, rank: int, world: int, per_rank_batch: int, drop_last: bool = True) -> List[List[int]]:
-    """Rounds of work for `rank`: round k covers global items [k*W*b, (k+1)*W*b), rank takes the
-    strided slice r::W of it (so every round is balanced and a round's items are contiguous on disk)."""
-    rounds: List[List[int]] = []
-    span = world * per_rank_batch
-    full = n_items // span
-    for k in range(full):
-        base = k * span
-        rounds.append(list(range(base + rank, base + span, world)))
-    rem = n_items - full * span
-    if rem and not drop_last:
-        base = full * span
-        mine = list(range(base + rank, n_items, world))
-        if mine:
-            rounds.append(mine)
-    return rounds
 
 
 def _buckets(tensors: Sequence[torch.Tensor], limit: int) -> Iterable[List[torch.Tensor]]:
@@ -98,9 +80,3 @@ def gather_images(images_u8: torch.Tensor, dst: int = 0) -> Optional[torch.Tenso
         return torch.cat(out, 0)
     dist.gather(images_u8, None, dst=dst)
     return None
-
-
-def interleave_rank_major(gathered: torch.Tensor, world: int) -> torch.Tensor:
-    """Undo the r::W striding of one round: rank-major [W*b, ...] -> global order [b*W, ...]."""
-    b = gathered.shape[0] // world
-    return gathered.view(world, b, *gathered.shape[1:]).transpose(0, 1).reshape(world * b, *gathered.shape[1:])

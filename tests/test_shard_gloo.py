@@ -39,8 +39,10 @@ def _worker(rank, world, port, q):
             objs = [ref]
         dist.broadcast_object_list(objs, src=0)
         same = all(torch.equal(got[k], objs[0][k]) for k in got)
-        # shard a work list of 11 items, per-rank batch 2 -> 2 full rounds, remainder dropped
-        rounds = shard.shard_indices(11, rank, world, 2, drop_last=True)
+        # the product's partition (pbe_amd.testbench.rank_batches): 11 items, batch 2 -> 5 full batches dealt round-robin, remainder dropped
+        from pbe_amd.testbench import rank_batches
+        mine = rank_batches(11, 2, rank, world)
+        rounds = [items for _, items in mine]
         # "compute": decode latents of my samples with the oracle on name-seeded narrow VAE weights
         keys = {}
         with open(os.path.join(os.path.dirname(__file__), "golden", "narrow_keys.txt")) as f:
@@ -55,11 +57,18 @@ def _worker(rank, world, port, q):
                 z = torch.cat([cases.synthetic_triples(1, 64, first_index=i)["x_T"] for i in rnd])
                 img = torch.clamp((O.first_stage_decode(sd, z, cases.VAE_NARROW, "first_stage_model.") + 1) / 2, 0, 1)
                 u8 = (img * 255).round().to(torch.uint8)
-                gathered = shard.gather_images(u8, dst=0)
+                outs.append(u8)
+            # ranks may hold different batch counts (5 batches over 2 ranks): gather batch by batch, padding the short rank
+            n_rounds = (5 + world - 1) // world
+            gathered = []
+            for k in range(n_rounds):
+                u8 = outs[k] if k < len(outs) else torch.zeros_like(outs[0])
+                g = shard.gather_images(u8, dst=0)
                 if rank == 0:
-                    outs.append(shard.interleave_rank_major(gathered, world))
+                    gathered.append(g)
+            outs = gathered
         if rank == 0:
-            q.put({"same": same, "info": info, "rounds": rounds, "images": torch.cat(outs)})
+            q.put({"same": same, "info": info, "rounds": rounds, "images": torch.stack(outs)})        # [round, rank-major 2*b, ...]
         else:
             q.put({"same": same, "info": info, "rounds": rounds})
     finally:
@@ -85,8 +94,8 @@ def test_two_rank_broadcast_shard_gather():
     assert all(r["info"]["messages"] >= 2 for r in res)                   # bucketed, not one message per tensor (9 tensors)
     r0 = next(r for r in res if "images" in r)
     r1 = next(r for r in res if "images" not in r)
-    assert r0["rounds"] == [[0, 2], [4, 6]] and r1["rounds"] == [[1, 3], [5, 7]]      # r::W inside each round, remainder (8..10) dropped
-    # single-process result on the same 8 samples, global order
+    assert r0["rounds"] == [[0, 1], [4, 5], [8, 9]] and r1["rounds"] == [[2, 3], [6, 7]]      # whole batches round-robin, item 10 dropped
+    # single-process result on the same 10 samples, global order
     keys = {}
     with open(os.path.join(os.path.dirname(__file__), "golden", "narrow_keys.txt")) as f:
         for line in f:
@@ -95,7 +104,63 @@ def test_two_rank_broadcast_shard_gather():
                 keys[k] = tuple(int(x) for x in s.split("x"))
     sd = {k: synth_tensor(k, s) for k, s in keys.items()}
     with torch.no_grad():
-        z = torch.cat([cases.synthetic_triples(1, 64, first_index=i)["x_T"] for i in range(8)])
-        ref = (torch.clamp((O.first_stage_decode(sd, z, cases.VAE_NARROW, "first_stage_model.") + 1) / 2, 0, 1) * 255).round().to(torch.uint8)
-    assert torch.equal(r0["images"], ref)
-    assert shard.shard_indices(11, 0, 2, 2, drop_last=False)[-1] == [8, 10]
+        ref = []                                         # batch by batch, like the ranks (CPU conv kernels pick algorithms by batch size)
+        for b0 in range(0, 10, 2):
+            z = torch.cat([cases.synthetic_triples(1, 64, first_index=i)["x_T"] for i in (b0, b0 + 1)])
+            ref.append((torch.clamp((O.first_stage_decode(sd, z, cases.VAE_NARROW, "first_stage_model.") + 1) / 2, 0, 1) * 255).round().to(torch.uint8))
+        ref = torch.cat(ref)
+    img = r0["images"]                                   # [3 rounds, 4 (rank 0's 2 then rank 1's 2), 3, H, W]
+    for k in range(3):
+        assert torch.equal(img[k, 0:2], ref[4 * k:4 * k + 2])                    # batch 2k on rank 0
+        if k < 2:
+            assert torch.equal(img[k, 2:4], ref[4 * k + 2:4 * k + 4])            # batch 2k+1 on rank 1
+
+
+# ---- bench.py's own launcher (python bench.py --gpus N with no RANK in the environment) --------------------------------
+def _run_bench(args, env_extra=None, launcher=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` starts its own two workers, relays rank 0's one JSON line and exits 0 (rehearsal: gloo, no GPU work)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"rehearsal": True, "n_gpus": 2, "rank_sum": 3.0, "steps": 2, "warmup": 1}
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_propagates_worker_failure():
+    r = _run_bench(["--gpus", "2", "--rehearse-launch"], env_extra={"PBE_BENCH_FAIL_RANK": "1"})
+    assert r.returncode == 3
+    assert "rank 1 exited with code 3" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 form: torch.distributed.run sets RANK/WORLD_SIZE, so bench.py must NOT launch again."""
+    import json
+    import sys
+    port = _free_port()
+    r = _run_bench(["--gpus", "2", "--rehearse-launch"],
+                   launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                             "--master-port", str(port)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _run_bench(["--gpus", "4", "--rehearse-launch"], env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
