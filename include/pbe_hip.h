@@ -47,6 +47,9 @@ typedef void* pbe_stream_t; /* hipStream_t */
 
 int pbe_abi_version(void);
 const char* pbe_last_error(void);
+/* sha256 (first 16 hex digits) over the sources and flags the library was built from (pbe_amd/build.py); the ctypes loader
+ * recomputes it from the tree and refuses a stale binary instead of silently running old kernels. */
+const char* pbe_source_hash(void);
 
 /* ---------------------------------------------------------------------------------------------
  * pbe_gemm_f16 — C[m,n] = act(alpha * sum_k A[m,k] * W[n,k] + bias + rowvec[m / group_rows, n]) + R[m,n]

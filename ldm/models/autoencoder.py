@@ -29,8 +29,8 @@ class AutoencoderKL(HipModule):
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
     def init_from_ckpt(self, path, ignore_keys=()):
-        sd = torch.load(path, map_location="cpu", weights_only=True)
-        sd = sd.get("state_dict", sd)
+        from pbe_amd.checkpoint import read_state_dict
+        sd = read_state_dict(path)
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         self.load_state_dict(sd, strict=False)
 

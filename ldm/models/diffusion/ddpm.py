@@ -112,9 +112,9 @@ class DDPM(nn.Module):
         yield None            # use_ema False: nothing to swap (ddpm.py:231-243)
 
     def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
+        from pbe_amd.checkpoint import read_state_dict
         from pbe_amd.weights import canonical_checkpoint_keys
-        sd = torch.load(path, map_location="cpu", weights_only=True)
-        sd = canonical_checkpoint_keys(sd.get("state_dict", sd))
+        sd = canonical_checkpoint_keys(read_state_dict(path))
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in (ignore_keys or ()))}
         missing, unexpected = (self.model if only_model else self).load_state_dict(sd, strict=False)
         print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
@@ -243,11 +243,13 @@ class LatentDiffusion(DDPM):
 
 def load_model_from_config(config, ckpt=None, device="cuda", verbose=False):
     """scripts/inference.py:58-75 counterpart: build from the config's ``model`` section and load a
-    Lightning checkpoint's ``state_dict`` (strict=False, EMA keys dropped, CLIP keys remapped)."""
+    Lightning checkpoint's ``state_dict`` (strict=False, EMA keys dropped, CLIP keys remapped).  The file is read
+    without executing anything from it (pbe_amd/checkpoint.py): foreign ``callbacks`` / ``hyper_parameters`` objects
+    of a Lightning file are skipped instead of failing the load."""
+    from pbe_amd.checkpoint import read_state_dict
     model = instantiate_from_config(config["model"])
     if ckpt:
-        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
-        m, u = model.load_state_dict(sd.get("state_dict", sd), strict=False)
+        m, u = model.load_state_dict(read_state_dict(ckpt, verbose=verbose), strict=False)
         if verbose:
             print("missing keys:", m, "\nunexpected keys:", u)
     return model.to(device).eval()

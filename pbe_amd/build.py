@@ -15,7 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libpbe_hip.so")
-SOURCES = ["runtime.hip", "igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+import importlib.util as _ilu
+
+_spec = _ilu.spec_from_file_location("_pbe_lib_for_build", os.path.join(HERE, "lib.py"))      # lib.py alone: no torch import at module level
+_libmod = _ilu.module_from_spec(_spec)
+_spec.loader.exec_module(_libmod)
+SOURCES = list(_libmod.SOURCES)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 # per-file extras: keep MFMA results in VGPRs where the VALU consumes them right away (attention softmax),
@@ -43,8 +48,12 @@ def _stale(target: str, deps) -> bool:
 def _compile(src: str, extra) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pbe_hip.h"), os.path.abspath(__file__)]
+    hash_flag = []
+    if src == "runtime.hip":                     # the library's identity: rebuilt whenever ANY source changed
+        hash_flag = [f'-DPBE_SRC_HASH="{_libmod.source_hash()}"']
+        deps = deps + [os.path.join(HERE, rel) for rel in _libmod.HASHED]
     if _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), *extra, *hash_flag, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -357,11 +357,8 @@ template <int DP, int QW, int KH = 1>
 static void launch_attn(const AttnP& p, hipStream_t s) {
     constexpr size_t lds = 2 * KH * AttnTile<DP>::BUF;
     static_assert(lds <= 160 * 1024, "attention tile exceeds the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH>), (int)lds);
     dim3 grid(cdiv(p.Nq, 128 * QW), p.B * p.H);
     hipLaunchKernelGGL((attn_kernel<DP, QW, KH>), grid, dim3(256), lds, s, p);
 }

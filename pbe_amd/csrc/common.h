@@ -90,3 +90,15 @@ __device__ __forceinline__ void apply_act4(float (&v)[4], int act) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel.  One bit per device remembers where it
+// has been raised; the call is idempotent, so two threads racing on the same bit merely repeat it (no lock, no UB).
+#include <atomic>
+static inline void pbe_raise_dynamic_lds(std::atomic<uint64_t>& done, const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}

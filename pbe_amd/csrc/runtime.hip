@@ -18,6 +18,10 @@ int pbe_set_error(int code, const char* fmt, ...) {
 
 extern "C" int pbe_abi_version(void) { return PBE_ABI_VERSION; }
 extern "C" const char* pbe_last_error(void) { return g_pbe_err; }
+#ifndef PBE_SRC_HASH
+#define PBE_SRC_HASH "unknown"
+#endif
+extern "C" const char* pbe_source_hash(void) { return PBE_SRC_HASH; }
 
 // ---- per-class timing: hipEvents recorded on the launch stream around each entry point ---------
 // Off by default (zero overhead: one relaxed load).  bench.py turns it on for ONE profiled pass

@@ -41,6 +41,7 @@ class AttnDesc(C.Structure):
 SYMBOLS = {
     "pbe_abi_version": (c_i32, []),
     "pbe_last_error": (C.c_char_p, []),
+    "pbe_source_hash": (C.c_char_p, []),
     "pbe_gemm_f16": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "pbe_conv3x3_f16": (c_i32, [C.POINTER(Conv3x3Desc), c_vp]),
     "pbe_im2col3x3_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -69,6 +70,20 @@ SYMBOLS = {
 
 _lib = None
 _lock = threading.Lock()
+
+SOURCES = ["runtime.hip", "igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+HASHED = [os.path.join("csrc", f) for f in SOURCES] + [os.path.join("csrc", "common.h"), os.path.join("..", "include", "pbe_hip.h"), "build.py"]
+
+
+def source_hash() -> str:
+    """Identity of what libpbe_hip.so must have been built from: every kernel source, the shared headers and build.py
+    (which holds the compiler flags).  build.py embeds it (-DPBE_SRC_HASH); load() compares."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in HASHED:
+        with open(os.path.join(_HERE, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
 
 
 class PbeError(RuntimeError):
@@ -100,6 +115,9 @@ def load() -> C.CDLL:
         v = lib.pbe_abi_version()
         if v != ABI_VERSION:
             raise PbeError(f"libpbe_hip.so ABI version {v} != expected {ABI_VERSION}")
+        built, want = lib.pbe_source_hash().decode(), source_hash()
+        if built != want and not os.environ.get("PBE_ALLOW_STALE_LIB"):
+            raise PbeError(f"libpbe_hip.so was built from other sources (binary {built}, tree {want}): run `python -m pbe_amd.build`")
         _lib = lib
     return _lib
 

@@ -27,13 +27,16 @@ def _clip_cfg(c, m):
                                             image_size=c["image"], patch_size=c["patch"], layer_norm_eps=c["eps"]), mapper_layers=m["layers"])}
 
 
-def narrow_model(device):
-    cfg = {"target": "ldm.models.diffusion.ddpm.LatentDiffusion",
+def narrow_config():
+    return {"target": "ldm.models.diffusion.ddpm.LatentDiffusion",
            "params": dict(linear_start=0.00085, linear_end=0.0120, num_timesteps_cond=1, log_every_t=200, timesteps=1000, first_stage_key="inpaint",
                           cond_stage_key="image", image_size=16, channels=4, cond_stage_trainable=True, conditioning_key="crossattn",
                           scale_factor=0.18215, use_ema=False, unet_config=_unet_cfg(cases.UNET_NARROW), first_stage_config=_vae_cfg(cases.VAE_NARROW),
                           cond_stage_config=_clip_cfg(cases.CLIP_NARROW, cases.MAPPER_NARROW), cond_embed_dim=cases.MAPPER_NARROW["width"])}
-    model = instantiate_from_config(cfg)
+
+
+def narrow_model(device):
+    model = instantiate_from_config(narrow_config())
     fill_latent_diffusion_(model)
     return model.to(device).eval()
 

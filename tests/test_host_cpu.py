@@ -10,6 +10,7 @@
 """
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -214,3 +215,83 @@ def test_preprocessing_of_bundled_example(golden_dir):
     assert set(torch.unique(t["mask"]).tolist()) == {0.0, 1.0} and 0.05 < 1 - t["mask"].mean().item() < 0.6
     from pbe_amd.pipeline import resize_mask
     assert torch.equal(resize_mask(t["mask"], (64, 64)), O.resize_mask(t["mask"], (64, 64), True))
+
+
+# ---- checkpoint files (reference scripts/inference.py:58-75, ddpm.py:245-260) -----------------------------
+def _narrow_reference_state_dict(golden_dir):
+    from pbe_amd.weights import synth_tensor
+    sd = {}
+    with open(os.path.join(golden_dir, "narrow_keys.txt")) as f:
+        for line in f:
+            k, s = line.split()
+            sd[k] = synth_tensor(k, tuple(int(x) for x in s.split("x")) if s != "scalar" else ())
+    return sd
+
+
+def test_lightning_checkpoint_is_read_without_its_packages(tmp_path, golden_dir):
+    """A Lightning-layout file whose pickle names pytorch_lightning / omegaconf classes: the weights-only loader refuses it,
+    the restricted reader returns exactly the tensors and resolves none of the foreign globals."""
+    import pickle
+    import ckpt_synth
+    from pbe_amd.checkpoint import read_state_dict
+    from pbe_amd.weights import canonical_checkpoint_keys
+    ref = {k: v for k, v in _narrow_reference_state_dict(golden_dir).items() if k.startswith(("model.diffusion_model.input_blocks.0", "cond_stage_model.transformer",
+                                                                                               "first_stage_model.quant", "proj_out", "learnable_vector", "betas"))}
+    path = str(tmp_path / "model.ckpt")
+    ckpt_synth.write_lightning_checkpoint(path, ref)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)
+    assert "pytorch_lightning" not in sys.modules and "omegaconf" not in sys.modules
+    sd = read_state_dict(path)
+    assert "pytorch_lightning" not in sys.modules and "omegaconf" not in sys.modules
+    assert any(k.startswith("model_ema.") for k in sd) and "model_ema.decay" in sd
+    can = canonical_checkpoint_keys(sd)
+    assert set(can) == set(ref)
+    for k, v in ref.items():
+        assert can[k].dtype == v.dtype and torch.equal(can[k], v), k
+    assert tuple(can["model.diffusion_model.input_blocks.0.0.weight"].shape)[1:] == (9, 3, 3)          # the 9-channel conv-in (modify_checkpoints.py:1-6)
+    # transformers >= 5 spelling of the CLIP keys maps back to the reference's `vision_model.` names
+    path5 = str(tmp_path / "model_hf5.ckpt")
+    ckpt_synth.write_lightning_checkpoint(path5, ref, hf5_clip_names=True, foreign=False)
+    sd5 = read_state_dict(path5)
+    assert not any("vision_model" in k for k in sd5)
+    can5 = canonical_checkpoint_keys(sd5)
+    assert set(can5) == set(ref) and all(torch.equal(can5[k], ref[k]) for k in ref)
+    # a bare state dict (what `torch.save(sd)` of scripts/modify_checkpoints.py writes) is accepted too
+    bare = str(tmp_path / "bare.ckpt")
+    torch.save({"state_dict": {k: v for k, v in ref.items()}}, bare)
+    assert set(read_state_dict(bare)) == set(ref)
+
+
+def test_restricted_reader_executes_nothing(tmp_path):
+    """A pickle that would run code on a full unpickle: the reader maps the callable to an inert placeholder."""
+    import pickle
+    from pbe_amd.checkpoint import CheckpointError, read_state_dict
+    marker = tmp_path / "pwned"
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    path = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {"w": torch.arange(6.0).reshape(2, 3)}, "callbacks": Boom()}, path)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)
+    sd = read_state_dict(path)
+    assert not marker.exists()
+    assert list(sd) == ["w"] and torch.equal(sd["w"], torch.arange(6.0).reshape(2, 3))
+    with open(str(tmp_path / "junk.ckpt"), "wb") as f:
+        f.write(b"not a checkpoint")
+    with pytest.raises((CheckpointError, pickle.UnpicklingError, Exception)):
+        read_state_dict(str(tmp_path / "junk.ckpt"))
+
+
+def test_loader_refuses_a_stale_binary(monkeypatch):
+    """The .so is git-ignored and travels with the tree: a kernel edit without a rebuild must not run the old binary silently."""
+    from pbe_amd import lib
+    handle = lib.load()
+    assert handle.pbe_source_hash().decode() == lib.source_hash()
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "source_hash", lambda: "0123456789abcdef")
+    with pytest.raises(lib.PbeError, match="built from other sources"):
+        lib.load()
