@@ -82,6 +82,10 @@ typedef struct pbe_gemm_desc {
     int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..8) | (split-K factor << 8), factor 0 = library's choice */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
+/* Plan / workspace query for the SAME descriptor (nothing is launched): out6 = {tile config index, split-K factor,
+ * tile rows BM, tile columns BN, workgroups, 0}; *workspace_needed = bytes of split-K scratch the plan uses (0 when the
+ * plan does not split).  A descriptor with a smaller workspace gets a smaller factor, never an error. */
+int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* workspace_needed);
 
 /* ---------------------------------------------------------------------------------------------
  * pbe_conv3x3_f16 — NHWC 3x3 convolution as an implicit GEMM on the matrix cores.
@@ -114,6 +118,7 @@ typedef struct pbe_conv3x3_desc {
                                divides C1 and C2 (0 = 32).  A pixel's 9 taps are then re-read within 9*cb/32 k-tiles (L2 hits) */
 } pbe_conv3x3_desc;
 int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
+int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t* workspace_needed); /* as pbe_gemm_plan */
 
 /* im2col for the three small-Cin convs (9->320 U-Net in, 3->128 VAE in, 4->512 VAE decoder in):
  * X fp16 NHWC [B,H,W,Cp] -> out fp16 [B*Ho*Wo, 9*Cp]. */

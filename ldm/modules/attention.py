@@ -183,11 +183,12 @@ class BasicTransformerBlock(HipModule):
         and the attention core do not depend on the context, so they run once at batch B; the two halves part where
         attn2's constant is added (the out-projection epilogue).  Returns [2B*N, C]."""
         p = self.pk()
-        a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
-        a1 = self.attn1.pk()
         x1 = torch.empty((2 * B * N, x2d.shape[1]), dtype=torch.float16, device=x2d.device)
-        for half in (0, 1):
-            ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec[half * B:(half + 1) * B], group_rows=N, resid=x2d, out=x1[half * B * N:(half + 1) * B * N])
+        with ops.pinned_batch_scale(2):              # batch-B launches take the split-K factor of the batch-2B layer: same bits
+            a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
+            a1 = self.attn1.pk()
+            for half in (0, 1):
+                ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec[half * B:(half + 1) * B], group_rows=N, resid=x2d, out=x1[half * B * N:(half + 1) * B * N])
         return self.ff.run(ops.layernorm(x1, p.g3, p.b3, p.eps3), resid=x1)
 
     def forward(self, x, context=None):
@@ -235,13 +236,15 @@ class SpatialTransformer(HipModule):
         B, H, W, Cc = x.shape
         N = H * W
         x2d = x.view(B * N, Cc)
-        h = ops.gemm(ops.groupnorm(x, p.g, p.b, p.eps, False).view(B * N, Cc), p.wi, p.bi)
+        with ops.pinned_batch_scale(2):
+            h = ops.gemm(ops.groupnorm(x, p.g, p.b, p.eps, False).view(B * N, Cc), p.wi, p.bi)
         h = self.transformer_blocks[0].run_paired(h, B, N, ctx_vecs[0])
         for blk, cv in zip(list(self.transformer_blocks)[1:], ctx_vecs[1:]):
             h = blk.run(h, 2 * B, N, cv)
         y = torch.empty((2 * B * N, Cc), dtype=torch.float16, device=x.device)
-        for half in (0, 1):
-            ops.gemm(h[half * B * N:(half + 1) * B * N], p.wo, p.bo, resid=x2d, out=y[half * B * N:(half + 1) * B * N])
+        with ops.pinned_batch_scale(2):
+            for half in (0, 1):
+                ops.gemm(h[half * B * N:(half + 1) * B * N], p.wo, p.bo, resid=x2d, out=y[half * B * N:(half + 1) * B * N])
         return y.view(2 * B, H, W, Cc)
 
     def forward(self, x, context=None):

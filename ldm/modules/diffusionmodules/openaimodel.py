@@ -262,8 +262,10 @@ class UNetModel(HipModule):
         cat([x]*2), cat([t]*2), cat([uc, c]) - both halves share x and t and differ ONLY in the context.  Then x16 holds the
         B shared inputs while timesteps / context hold 2B rows, and everything upstream of the first context-dependent
         operation (conv_in, the first ResBlock, the first transformer's GroupNorm / proj_in / LayerNorm / q,k,v /
-        attention core) is computed once and serves both halves.  Exact common-subexpression elimination: every kernel
-        is deterministic and per-sample, so the duplicated evaluation would reproduce the same bits."""
+        attention core) is computed once and serves both halves.  Common-subexpression elimination: every kernel is
+        deterministic and per-sample, and the only batch-dependent choice that changes bits - the split-K factor, i.e. the
+        fp32 summation order - is pinned to the batch-2B choice, so the duplicated evaluation gives the same bits
+        (tools/layer_diff.py shows where un-pinned batch sizes part ways)."""
         p = self.pk()
         ctx = self.context_vectors(context)
         t_emb = timestep_embedding(timesteps, self.model_channels)
@@ -276,10 +278,13 @@ class UNetModel(HipModule):
             first = list(blocks[0])
             if timesteps.shape[0] != 2 * B or len(first) != 2 or not isinstance(first[0], ResBlock) or not isinstance(first[1], SpatialTransformer):
                 raise PbeError("UNetModel.forward_nhwc(paired=True): needs 2B timesteps and a [ResBlock, SpatialTransformer] first block")
-            h0 = ops.conv3x3_small(x16, p.w_in, p.b_in)
-            off, n = p.emb_off[id(first[0])]
-            r = first[0].run(h0, emb_all[:B, off:off + n])
-            h = first[1].run_paired(r, ctx[id(first[1])])
+            # the prefix runs at batch B with the tile config / split-K factor of batch 2B (ops.pinned_batch_scale): it
+            # reproduces the duplicated evaluation bit for bit (tests/test_model_gpu.py::test_full_unet_shared_guidance_prefix)
+            with ops.pinned_batch_scale(2):
+                h0 = ops.conv3x3_small(x16, p.w_in, p.b_in)
+                off, n = p.emb_off[id(first[0])]
+                r = first[0].run(h0, emb_all[:B, off:off + n])
+            h = first[1].run_paired(r, ctx[id(first[1])])          # pins its own batch-B launches
             hs = [torch.cat([h0, h0], 0), h]
             blocks = blocks[1:]
         else:

@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
 }
 
 // ---- host side --------------------------------------------------------------------------------
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 struct Plan { int cfg; int splits; };
 struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
 // eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP)
@@ -561,25 +562,22 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
-static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
-    PBE_REQUIRE(d && d->A && d->W && d->C, "pbe_gemm_f16: null operand");
-    PBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1 && d->batch <= 65535, "pbe_gemm_f16: bad dims M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
-    PBE_REQUIRE(d->K % 8 == 0, "pbe_gemm_f16: K=%d must be a multiple of 8", d->K);
-    PBE_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && al16(d->A) && al16(d->W), "pbe_gemm_f16: A/W must be 16-byte aligned with ld %% 8 == 0");
-    PBE_REQUIRE(d->strideA % 8 == 0 && d->strideW % 8 == 0, "pbe_gemm_f16: batch strides of A/W must be multiples of 8");
+static int fill_gemm(const pbe_gemm_desc* d, IGemmP& p, const char* who) {
+    PBE_REQUIRE(d && d->A && d->W && d->C, "%s: null operand", who);
+    PBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1 && d->batch <= 65535, "%s: bad dims M=%d N=%d K=%d batch=%d", who, d->M, d->N, d->K, d->batch);
+    PBE_REQUIRE(d->K % 8 == 0, "%s: K=%d must be a multiple of 8", who, d->K);
+    PBE_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && al16(d->A) && al16(d->W), "%s: A/W must be 16-byte aligned with ld %% 8 == 0", who);
+    PBE_REQUIRE(d->strideA % 8 == 0 && d->strideW % 8 == 0, "%s: batch strides of A/W must be multiples of 8", who);
     const int K1 = d->A2 ? d->K1 : d->K;
     if (d->A2) {
         PBE_REQUIRE(K1 > 0 && K1 < d->K && K1 % 32 == 0 && d->lda2 % 8 == 0 && al16(d->A2) && d->batch == 1,
-                    "pbe_gemm_f16: split-K source needs K1 %% 32 == 0 (K1=%d), aligned A2, batch 1", K1);
+                    "%s: split-K source needs K1 %% 32 == 0 (K1=%d), aligned A2, batch 1", who, K1);
     }
-    PBE_REQUIRE(d->lda >= (d->A2 ? K1 : d->K) && d->ldw >= d->K, "pbe_gemm_f16: leading dims too small");
-    PBE_REQUIRE(!d->rowvec || d->group_rows > 0, "pbe_gemm_f16: rowvec needs group_rows > 0");
+    PBE_REQUIRE(d->lda >= (d->A2 ? K1 : d->K) && d->ldw >= d->K, "%s: leading dims too small", who);
+    PBE_REQUIRE(!d->rowvec || d->group_rows > 0, "%s: rowvec needs group_rows > 0", who);
     const bool geglu = d->act == PBE_ACT_GEGLU;
     const int Nout = geglu ? d->N / 2 : d->N;
-    PBE_REQUIRE(!geglu || (d->N % 16 == 0 && !d->resid && !d->rowvec && !d->bias_per_row), "pbe_gemm_f16: GEGLU epilogue needs N %% 16 == 0 and no resid/rowvec");
-    IGemmP p;
+    PBE_REQUIRE(!geglu || (d->N % 16 == 0 && !d->resid && !d->rowvec && !d->bias_per_row), "%s: GEGLU epilogue needs N %% 16 == 0 and no resid/rowvec", who);
     memset(&p, 0, sizeof(p));
     p.A = (const h16*)d->A; p.A2 = (const h16*)d->A2; p.W = (const h16*)d->W; p.C = (h16*)d->C;
     p.bias = d->bias; p.rowvec = (const h16*)d->rowvec; p.resid = (const h16*)d->resid;
@@ -588,34 +586,58 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     p.ldv = d->ldv; p.group_rows = d->group_rows > 0 ? d->group_rows : 1;
     p.sA = d->strideA; p.sW = d->strideW; p.sC = d->strideC; p.sR = d->strideR;
     p.alpha = d->alpha; p.act = d->act; p.bias_row = d->bias_per_row;
-    PBE_REQUIRE(d->ldc >= Nout, "pbe_gemm_f16: ldc too small");
+    PBE_REQUIRE(d->ldc >= Nout, "%s: ldc too small", who);
     p.vec = (Nout % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
     p.ws = (float*)d->workspace;
+    return PBE_OK;
+}
+
+extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
+    IGemmP p;
+    const int rc = fill_gemm(d, p, "pbe_gemm_f16");
+    if (rc != PBE_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     PBE_LAUNCH_CHECK("pbe_gemm_f16");
     return PBE_OK;
 }
 
-extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
-    PBE_REQUIRE(d && d->X && d->Wp && d->Y, "pbe_conv3x3_f16: null operand");
+static void report_plan(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int32_t* out) {
+    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg);
+    const TileCfg& t = kCfg[pl.cfg];
+    out[0] = pl.cfg; out[1] = pl.splits; out[2] = t.bm; out[3] = t.bn;
+    out[4] = cdiv(p.M, t.bm) * cdiv(p.N, t.bn) * batch * pl.splits;                       // workgroups launched
+    out[5] = 0;
+}
+
+extern "C" int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* workspace_needed) {
+    PBE_REQUIRE(out6 && workspace_needed, "pbe_gemm_plan: null output");
+    IGemmP p;
+    const int rc = fill_gemm(d, p, "pbe_gemm_plan");
+    if (rc != PBE_OK) return rc;
+    report_plan(p, d->batch, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6);
+    *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
+    return PBE_OK;
+}
+
+static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
+    PBE_REQUIRE(d && d->X && d->Wp && d->Y, "%s: null operand", who);
     const int Cin = d->C1 + d->C2;
-    PBE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "pbe_conv3x3_f16: bad dims");
-    PBE_REQUIRE(d->C1 > 0 && d->C1 % 32 == 0 && d->C2 >= 0 && d->C2 % 32 == 0, "pbe_conv3x3_f16: C1=%d C2=%d must be multiples of 32 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", d->C1, d->C2);
-    PBE_REQUIRE((d->C2 == 0) == (d->X2 == nullptr), "pbe_conv3x3_f16: X2 / C2 mismatch");
-    PBE_REQUIRE(d->stride == 1 || d->stride == 2, "pbe_conv3x3_f16: stride must be 1 or 2");
-    PBE_REQUIRE(d->pad == 0 || d->pad == 1, "pbe_conv3x3_f16: pad must be 0 or 1");
-    PBE_REQUIRE(d->upsample == 0 || (d->upsample == 1 && d->stride == 1), "pbe_conv3x3_f16: upsample only with stride 1");
-    PBE_REQUIRE(al16(d->X) && al16(d->Wp) && al16(d->Y) && (!d->X2 || al16(d->X2)), "pbe_conv3x3_f16: 16-byte alignment");
+    PBE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: bad dims", who);
+    PBE_REQUIRE(d->C1 > 0 && d->C1 % 32 == 0 && d->C2 >= 0 && d->C2 % 32 == 0, "%s: C1=%d C2=%d must be multiples of 32 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", who, d->C1, d->C2);
+    PBE_REQUIRE((d->C2 == 0) == (d->X2 == nullptr), "%s: X2 / C2 mismatch", who);
+    PBE_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2", who);
+    PBE_REQUIRE(d->pad == 0 || d->pad == 1, "%s: pad must be 0 or 1", who);
+    PBE_REQUIRE(d->upsample == 0 || (d->upsample == 1 && d->stride == 1), "%s: upsample only with stride 1", who);
+    PBE_REQUIRE(al16(d->X) && al16(d->Wp) && al16(d->Y) && (!d->X2 || al16(d->X2)), "%s: 16-byte alignment", who);
     const int Hv = d->H << d->upsample, Wv = d->W << d->upsample;
     // output size: pad=1 -> floor((Hv + 2 - 3)/s) + 1 ; pad=0 is the VAE (0,1,0,1) pad: floor((Hv + 1 - 3)/s) + 1
     const int extra = d->pad ? 2 : 1;
     const int Ho = (Hv + extra - 3) / d->stride + 1, Wo = (Wv + extra - 3) / d->stride + 1;
-    PBE_REQUIRE(Ho > 0 && Wo > 0, "pbe_conv3x3_f16: empty output");
+    PBE_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
     const long M = (long)d->B * Ho * Wo;
-    PBE_REQUIRE(M < (1L << 31), "pbe_conv3x3_f16: too many output pixels");
-    IGemmP p;
+    PBE_REQUIRE(M < (1L << 31), "%s: too many output pixels", who);
     memset(&p, 0, sizeof(p));
     p.A = (const h16*)d->X; p.A2 = (const h16*)d->X2; p.W = (const h16*)d->Wp; p.C = (h16*)d->Y;
     p.bias = d->bias; p.rowvec = (const h16*)d->rowvec; p.resid = (const h16*)d->resid;
@@ -627,10 +649,27 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     p.H = d->H; p.Wd = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Ho = Ho; p.Wo = Wo;
     p.cstride = d->stride; p.pad = d->pad; p.ups = d->upsample;
     p.cb = d->kblock > 0 ? d->kblock : 32;
-    PBE_REQUIRE(p.cb % 32 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "pbe_conv3x3_f16: kblock=%d must be a multiple of 32 dividing C1=%d and C2=%d", p.cb, d->C1, d->C2);
+    PBE_REQUIRE(p.cb % 32 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "%s: kblock=%d must be a multiple of 32 dividing C1=%d and C2=%d", who, p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
+    return PBE_OK;
+}
+
+extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
+    IGemmP p;
+    const int rc = fill_conv(d, p, "pbe_conv3x3_f16");
+    if (rc != PBE_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     dispatch_igemm<1>(p, 1, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     PBE_LAUNCH_CHECK("pbe_conv3x3_f16");
+    return PBE_OK;
+}
+
+extern "C" int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t* workspace_needed) {
+    PBE_REQUIRE(out6 && workspace_needed, "pbe_conv3x3_plan: null output");
+    IGemmP p;
+    const int rc = fill_conv(d, p, "pbe_conv3x3_plan");
+    if (rc != PBE_OK) return rc;
+    report_plan(p, 1, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6);
+    *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
     return PBE_OK;
 }

@@ -44,6 +44,8 @@ SYMBOLS = {
     "pbe_source_hash": (C.c_char_p, []),
     "pbe_gemm_f16": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "pbe_conv3x3_f16": (c_i32, [C.POINTER(Conv3x3Desc), c_vp]),
+    "pbe_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_sz)]),
+    "pbe_conv3x3_plan": (c_i32, [C.POINTER(Conv3x3Desc), C.POINTER(c_i32), C.POINTER(c_sz)]),
     "pbe_im2col3x3_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_groupnorm_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "pbe_groupnorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp, c_sz, c_vp]),

@@ -56,6 +56,58 @@ try:
 except (OSError, ValueError):
     _TUNED = {}
 _RECORD = None            # set to a dict by tools/autotune.py to collect the shapes a workload uses
+_PLANS = None             # set to a list by tools/layer_diff.py: (key, tile config, split-K factor, BM, BN, workgroups) per GEMM / conv launch
+_PIN_SCALE = 1            # see pinned_batch_scale
+_PIN_CACHE = {}
+
+
+class pinned_batch_scale:
+    """Inside this context every GEMM / conv is launched with the tile config and split-K factor the library would pick for
+    the SAME layer at `scale` times the batch.  The k order of a tile does not depend on the tile shape; only the split-K
+    factor changes the fp32 summation order, so a sub-batch evaluated this way reproduces the bits of the full batch
+    (used by the shared guidance prefix: B samples evaluated once must equal the 2B duplicated evaluation)."""
+
+    def __init__(self, scale: int):
+        self.scale = int(scale)
+
+    def __enter__(self):
+        global _PIN_SCALE
+        self.prev, _PIN_SCALE = _PIN_SCALE, self.scale
+
+    def __exit__(self, *exc):
+        global _PIN_SCALE
+        _PIN_SCALE = self.prev
+        return False
+
+
+def _plan_of(desc, conv: bool):
+    out, need = (C.c_int32 * 6)(), C.c_size_t()
+    lib = _l.load()
+    _l.check((lib.pbe_conv3x3_plan if conv else lib.pbe_gemm_plan)(C.byref(desc), out, C.byref(need)), "plan")
+    return list(out), int(need.value)
+
+
+def _pinned_cfg(desc, key_fn, conv: bool, field: str = "M") -> int:
+    """tile_cfg for `desc` under pinned_batch_scale: the plan of the scaled problem, cached per key."""
+    key = key_fn(_PIN_SCALE)
+    hit = _PIN_CACHE.get(key)
+    if hit is None:
+        big = type(desc).from_buffer_copy(desc)
+        if conv:
+            big.B = desc.B * _PIN_SCALE
+        else:
+            setattr(big, field, getattr(desc, field) * _PIN_SCALE)
+        big.tile_cfg = int(_TUNED.get(key, -1))
+        pl, _ = _plan_of(big, conv)
+        hit = pl[0] | (max(1, pl[1]) << 8)
+        _PIN_CACHE[key] = hit
+    return hit
+
+
+def _launch_note(desc, key: str, conv: bool):
+    if _PLANS is not None:
+        pl, _ = _plan_of(desc, conv)
+        _PLANS.append((key, *pl[:5]))
 _TIMES = None             # set to a dict by tools/shape_profile.py: key -> [(start event, end event), ...] around each launch
 
 
@@ -153,6 +205,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d = _l.GemmDesc(_p(a), _p(a2), _p(w), _p(_h(out, "gemm out")), _p(bias), _p(rowvec), _p(resid), M, N, K, K1, lda, lda2, ldw, ldc, ldr,
                     ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0,
                     _splitk_ws(a.device).data_ptr(), SPLITK_WS_BYTES, _tile_cfg(f"g:{M}:{N}:{K}:{batch}"))
+    if _PIN_SCALE != 1:
+        if a.dim() == 3:                        # per-sample strided batch (V^T projection): the batch count scales, not M
+            d.tile_cfg = _pinned_cfg(d, lambda sc: f"g:{M}:{N}:{K}:{batch * sc}", False, "batch")
+        else:
+            d.tile_cfg = _pinned_cfg(d, lambda sc: f"g:{M * sc}:{N}:{K}:1", False)
+    _launch_note(d, f"g:{M}:{N}:{K}:{batch}", False)
     with _timed(f"g:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}{'v' if rowvec is not None else ''}"):
         _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
     return out
@@ -198,6 +256,9 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
     d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
                        1 if upsample else 0, ldv, act, _splitk_ws(x.device).data_ptr(), SPLITK_WS_BYTES,
                        _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"), conv_kblock(C1, C2))
+    if _PIN_SCALE != 1:
+        d.tile_cfg = _pinned_cfg(d, lambda sc: f"c:{B * sc}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}", True)
+    _launch_note(d, f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}", True)
     with _timed(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"):
         _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
     return y
