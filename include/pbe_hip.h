@@ -222,9 +222,15 @@ int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t B, int32_t 
 /* pbe_image_post_f32 — scripts/inference.py:347: clamp((x+1)/2, 0, 1) of fp16 NHWC [B,HW,ld] -> fp32 NCHW [B,3,HW]. */
 int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32_t ld, pbe_stream_t stream);
 
+/* pbe_resize_bilinear_f32 — scripts/inference.py:332 `Resize([h, w])(mask)` on fp32 planes [planes, Hin, Win] -> [planes, Hout, Wout]:
+ * bilinear, align_corners = False; antialias = 1 is the triangle filter of torchvision >= 0.17 (F.interpolate(antialias=True)),
+ * antialias = 0 the 2-tap form of the reference's pinned torchvision 0.12. */
+int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t Hin, int32_t Win, int32_t Hout,
+                            int32_t Wout, int32_t antialias, pbe_stream_t stream);
+
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
- * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2).
+ * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the 8-wave tiles (0/1).
  */
 int pbe_tune(int32_t key, int32_t value);
 

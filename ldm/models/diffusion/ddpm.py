@@ -30,6 +30,27 @@ def disabled_train(self, mode=True):
     return self
 
 
+class HipLinear(nn.Linear):
+    """``nn.Linear`` under the reference's parameter names whose forward is the HIP GEMM (fp16 operands, fp32 accumulate, bias in
+    the epilogue).  Used for ``proj_out`` (latent_diffusion.py:112) so that ``model.proj_out(c)`` called the reference's way
+    (scripts/inference.py:327) runs the same kernel as the rest of the path instead of an ATen / rocBLAS dispatch."""
+
+    def _packed(self):
+        key = (self.weight.data_ptr(), self.weight._version, self.bias.data_ptr(), self.bias._version)
+        c = self.__dict__.get("_pk")
+        if c is None or c[0] != key:
+            c = (key, ops.pack_linear(self.weight), f32(self.bias))
+            self.__dict__["_pk"] = c
+        return c[1], c[2]
+
+    def forward(self, z):
+        require_gpu(z, "proj_out")
+        w, b = self._packed()
+        lead = z.shape[:-1]
+        y = ops.gemm(z.to(torch.float16).reshape(-1, z.shape[-1]).contiguous(), w, b)
+        return y.view(*lead, -1)
+
+
 class DiffusionWrapper(nn.Module):
     def __init__(self, diff_model_config, conditioning_key):
         super().__init__()
@@ -145,7 +166,7 @@ class LatentDiffusion(DDPM):
         ignore_keys = kwargs.pop("ignore_keys", [])
         super().__init__(conditioning_key=conditioning_key, *args, **kwargs)
         self.learnable_vector = nn.Parameter(torch.randn((1, 1, cond_context_dim)), requires_grad=False)   # latent_diffusion.py:111
-        self.proj_out = nn.Linear(cond_embed_dim, cond_context_dim)                                          # latent_diffusion.py:112
+        self.proj_out = HipLinear(cond_embed_dim, cond_context_dim)                                          # latent_diffusion.py:112
         self.concat_mode, self.cond_stage_trainable, self.cond_stage_key = concat_mode, cond_stage_trainable, cond_stage_key
         try:
             self.num_downs = len(first_stage_config["params"]["ddconfig"]["ch_mult"]) - 1
@@ -165,16 +186,9 @@ class LatentDiffusion(DDPM):
             self.restarted_from_ckpt = True
         for p in self.parameters():
             p.requires_grad_(False)
-        self.__dict__["_proj_pack"] = None
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        self.__dict__["_proj_pack"] = None
-        return r
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         from pbe_amd.weights import canonical_checkpoint_keys
-        self.__dict__["_proj_pack"] = None
         return super().load_state_dict(canonical_checkpoint_keys(state_dict), strict=strict, **kw)
 
     # ---- conditioning ---------------------------------------------------------------------------
@@ -188,14 +202,8 @@ class LatentDiffusion(DDPM):
         return getattr(m, self.cond_stage_forward)(c)
 
     def project_conditioning(self, z):
-        """``model.proj_out(c)`` of scripts/inference.py:327 as a HIP GEMM: [B,1,1024] -> [B,1,768] fp16."""
-        pk = self.__dict__.get("_proj_pack")
-        if pk is None:
-            pk = (ops.pack_linear(self.proj_out.weight), f32(self.proj_out.bias))
-            self.__dict__["_proj_pack"] = pk
-        require_gpu(z, "proj_out")
-        B, n, d = z.shape
-        return ops.gemm(z.to(torch.float16).reshape(B * n, d).contiguous(), pk[0], pk[1]).view(B, n, -1)
+        """``model.proj_out(c)`` of scripts/inference.py:327: [B,1,1024] -> [B,1,768] fp16 (kept as an alias of the module call)."""
+        return self.proj_out(z)
 
     # ---- first stage -----------------------------------------------------------------------------
     @torch.no_grad()
@@ -237,7 +245,6 @@ class LatentDiffusion(DDPM):
         for m in self.modules():
             if isinstance(m, HipModule):
                 m.pk()
-        self.project_conditioning  # noqa: B018  (packed lazily, tiny)
         return self
 
 

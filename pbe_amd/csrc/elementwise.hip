@@ -280,3 +280,65 @@ extern "C" int pbe_bcast_row_f16(const void* a, const void* b, void* Y, int32_t 
     hipLaunchKernelGGL(bcast_row_kernel, EW_GRID(total), dim3(256), 0, s, (const h16*)a, (const h16*)b, (h16*)Y, C, (long)y_bs, total);
     EW_END(s, (double)total * 6.0, "pbe_bcast_row_f16");
 }
+
+// ---- bilinear resize of fp32 planes (mask 512x512 -> 64x64: scripts/inference.py:332 `Resize([h, w])`) -------------------------
+// antialias = 1: the triangle filter torchvision >= 0.17 applies to tensors (support = scale, weights normalised per output
+// pixel; row sums first, then the column combination - the order of ATen's upsample_bilinear2d_aa); antialias = 0: plain 2-tap
+// bilinear, align_corners = False (torchvision 0.12, the reference's pinned version).  One thread per output pixel.
+#define RS_MAX_TAPS 64
+__global__ void resize_bilinear_kernel(const float* src, float* dst, int Hin, int Win, int Hout, int Wout, float sh, float sw, int aa, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wout);
+    const long t = i / Wout;
+    const int oy = (int)(t % Hout);
+    const float* pl = src + (t / Hout) * (long)Hin * Win;
+    if (!aa) {
+        const float fy = fmaxf(sh * (oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * (ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0;
+        dst[i] = (1.f - ly) * ((1.f - lx) * pl[(long)y0 * Win + x0] + lx * pl[(long)y0 * Win + x1]) +
+                 ly * ((1.f - lx) * pl[(long)y1 * Win + x0] + lx * pl[(long)y1 * Win + x1]);
+        return;
+    }
+    const float sup_h = sh >= 1.f ? sh : 1.f, sup_w = sw >= 1.f ? sw : 1.f;
+    const float inv_h = sh >= 1.f ? 1.f / sh : 1.f, inv_w = sw >= 1.f ? 1.f / sw : 1.f;
+    const float cy = sh * (oy + 0.5f), cx = sw * (ox + 0.5f);
+    const int ymin = max((int)(cy - sup_h + 0.5f), 0), ysize = min((int)(cy + sup_h + 0.5f), Hin) - ymin;
+    const int xmin = max((int)(cx - sup_w + 0.5f), 0), xsize = min((int)(cx + sup_w + 0.5f), Win) - xmin;
+    float wx[RS_MAX_TAPS];
+    float tw = 0.f;
+    for (int j = 0; j < xsize; ++j) {
+        const float a = fabsf((j + xmin - cx + 0.5f) * inv_w);
+        wx[j] = a < 1.f ? 1.f - a : 0.f;
+        tw += wx[j];
+    }
+    const float nx = tw != 0.f ? 1.f / tw : 0.f;
+    float wy_tot = 0.f, acc = 0.f;
+    for (int k = 0; k < ysize; ++k) {
+        const float a = fabsf((k + ymin - cy + 0.5f) * inv_h);
+        wy_tot += a < 1.f ? 1.f - a : 0.f;
+    }
+    const float ny = wy_tot != 0.f ? 1.f / wy_tot : 0.f;
+    for (int k = 0; k < ysize; ++k) {
+        const float a = fabsf((k + ymin - cy + 0.5f) * inv_h);
+        const float wy = (a < 1.f ? 1.f - a : 0.f) * ny;
+        const float* row = pl + (long)(ymin + k) * Win + xmin;
+        float r = 0.f;
+        for (int j = 0; j < xsize; ++j) r += row[j] * (wx[j] * nx);
+        acc += r * wy;
+    }
+    dst[i] = acc;
+}
+extern "C" int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                                       int32_t antialias, pbe_stream_t stream) {
+    PBE_REQUIRE(src && dst && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "pbe_resize_bilinear_f32: bad arguments");
+    const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+    PBE_REQUIRE(!antialias || (2.f * fmaxf(sw, 1.f) + 2.f <= (float)RS_MAX_TAPS), "pbe_resize_bilinear_f32: horizontal scale %.2f needs more than %d taps", sw, RS_MAX_TAPS);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)planes * Hout * Wout;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(resize_bilinear_kernel, EW_GRID(total), dim3(256), 0, s, src, dst, Hin, Win, Hout, Wout, sh, sw, antialias ? 1 : 0, total);
+    EW_END(s, 4.0 * ((double)planes * Hin * Win + (double)total), "pbe_resize_bilinear_f32");
+}

@@ -52,8 +52,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4, bool PP = false>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    // PP (8-wave tiles only): "ping-pong" main loop.  Waves w and w + 4 share a SIMD; the two wave groups run the same
+    // [R: fragment reads + DMA issue | M: MFMAs] sequence offset by ONE barrier, so while one group's MFMAs own the
+    // SIMD's matrix pipe its partner's LDS reads, address arithmetic and LDS-DMA issue run in their shadow (without the
+    // stagger both waves of a SIMD read at the same time and then contend for the pipe: the read latency is exposed
+    // once per k-tile).  Two raw barriers per k-tile; see the hazard notes at the loop.
     // S = LDS ring depth (4: three k-tiles in flight, one workgroup per CU for the big tiles; 2: one in flight, the
     // smaller ring lets 2-4 workgroups share a CU so their prologues / epilogues overlap - shallow-K problems).
     constexpr int NW = NWM * NWN, NT = NW * 64;
@@ -220,6 +225,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     for (int t = 0; t < D; ++t)
         if (kt0 + t < nk) issue(kt0 + t);
 
+    if constexpr (!PP) {
     for (int kt = kt0; kt < nk; ++kt) {
         const int rem = nk - 1 - kt;                 // tiles issued after tile kt that may stay in flight
         if (rem >= D - 1) wait_vmcnt<(D - 1) * LPT>();
@@ -244,6 +250,53 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             for (int j = 0; j < TM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+    }
+    } else {
+        static_assert(!PP || (NW == 8 && S == 4), "ping-pong needs two waves per SIMD and the 4-slot ring");
+        // Barriers b0, b1, ... as group 0 (waves 0-3) counts them: group 0 runs R(kt) | b(2i) | M(kt) | b(2i+1), group 1
+        // (waves 4-7) passes one extra barrier first and therefore runs R(kt) between b(2i) and b(2i+1).
+        //   RAW: a wave retires its own DMAs of tile kt+1 (counted vmcnt) at the END of R(kt), i.e. before b(2i) / b(2i+1);
+        //        tile kt+1 is first read by group 0 after b(2i+1) - one barrier after every wave's wait.
+        //   WAR: DMA(kt+3) overwrites slot (kt-1) % 4.  Its last readers (group 1, R(kt-1)) complete their reads
+        //        (lgkmcnt(0)) before b(2i-1); the earliest issue (group 0, R(kt)) comes after b(2i-1).
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+        if (kt0 < nk) {
+            const int rem0 = nk - 1 - kt0;
+            if (rem0 >= D - 1) wait_vmcnt<(D - 1) * LPT>();
+            else if (rem0 == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // tile kt0 landed for every wave
+        if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
+        for (int kt = kt0; kt < nk; ++kt) {
+            const unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
+            const unsigned char* sw = sa + A_BYTES;
+            h16x8 fa[TM], fw[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + D < nk) issue(kt + D);
+            const int rem = nk - 2 - kt;             // tiles issued after tile kt+1 that may stay in flight
+            if (rem >= D - 1) wait_vmcnt<(D - 1) * LPT>();
+            else if (rem == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();            // end of R: my fragments are in registers, my share of tile kt+1 landed
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();            // end of M
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last M phase
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -514,8 +567,13 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     return best;
 }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4>
+int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): staggered two-group main loop for the 8-wave tiles
+
+template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4, bool PP = false>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
+    if constexpr (!PP && NWM * NWN == 8 && S == 4) {
+        if (g_pbe_pingpong) { launch_cfg<BM, BN, NWM, NWN, MODE, S, true>(p, batch, s); return; }
+    }
     constexpr size_t ring = S * (BM + BN) * 64;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0) +
@@ -523,12 +581,12 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, PP>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     pbe_prof_begin(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, PP>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch);
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
@@ -559,6 +617,7 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 1) { g_pbe_force_cfg = (value >= 0 && (value & 255) < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
+    if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 

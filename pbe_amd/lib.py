@@ -63,6 +63,7 @@ SYMBOLS = {
     "pbe_clip_patchify_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_bcast_row_f16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "pbe_image_post_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "pbe_resize_bilinear_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_tune": (c_i32, [c_i32, c_i32]),
     "pbe_prof_enable": (c_i32, [c_i32]),
     "pbe_prof_reset": (c_i32, []),

@@ -446,6 +446,17 @@ def clip_patchify(pixels: torch.Tensor, patch: int, kp: int) -> torch.Tensor:
     return y
 
 
+def resize_bilinear(x: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
+    """fp32 [B, C, H, W] -> [B, C, h, w], bilinear, align_corners=False (the mask resize of scripts/inference.py:332)."""
+    _f(x, "resize_bilinear x")
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    h, w = int(size[0]), int(size[1])
+    y = torch.empty((B, Cc, h, w), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().pbe_resize_bilinear_f32(_p(x), _p(y), B * Cc, H, W, h, w, 1 if antialias else 0, _stream()), "pbe_resize_bilinear_f32")
+    return y
+
+
 def bcast_row(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, B: int, y_bs: int) -> None:
     """out[bi * y_bs + c] = a[c] + b[c] for bi < B."""
     _h(a, "bcast_row a"); _h(b, "bcast_row b"); _h(out, "bcast_row out")

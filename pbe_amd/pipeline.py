@@ -8,7 +8,6 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -16,8 +15,8 @@ from . import ops
 def resize_mask(mask: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     """scripts/inference.py:332 ``Resize([h, w])(mask)``: bilinear, align_corners=False; the
     antialias default differs across torchvision versions -> exposed, default True.
-    Pre-processing: runs once per image, on whatever device the mask is on."""
-    return F.interpolate(mask.float(), size=tuple(size), mode="bilinear", align_corners=False, antialias=antialias)
+    Pre-processing, once per image: the HIP kernel pbe_resize_bilinear_f32 (no torch fallback)."""
+    return ops.resize_bilinear(mask.float(), size, antialias)
 
 
 @torch.no_grad()
@@ -35,7 +34,7 @@ def inpaint(model, image: torch.Tensor, mask: torch.Tensor, ref: torch.Tensor, *
     if timings is not None:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-    c = model.project_conditioning(model.get_learned_conditioning(ref))                  # inference.py:326-327
+    c = model.proj_out(model.get_learned_conditioning(ref))                              # inference.py:326-327
     uc = model.learnable_vector if scale != 1.0 else None                                # inference.py:323-325
     if ev:
         ev[1].record()

@@ -65,7 +65,6 @@ def broadcast_weights_(module: torch.nn.Module, src: int = 0, bucket_bytes: int 
     for m in module.modules():
         if hasattr(m, "invalidate_packs"):
             m.invalidate_packs()
-    module.__dict__["_proj_pack"] = None
     return {"bytes": float(total), "messages": float(msgs)}
 
 

@@ -72,7 +72,6 @@ def fill_latent_diffusion_(model: torch.nn.Module, seed: int = 0) -> None:
     for m in model.modules():
         if hasattr(m, "invalidate_packs"):
             m.invalidate_packs()
-    model.__dict__["_proj_pack"] = None
 
 
 # --- checkpoint key handling (scripts/inference.py:58-75, ddpm.py:245-260) -------------------

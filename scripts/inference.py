@@ -93,7 +93,7 @@ def main(argv=None):
         test_model_kwargs = {"inpaint_mask": t["mask"].to(device), "inpaint_image": t["inpaint"].to(device)}
         ref = t["ref"].to(device)
         uc = model.learnable_vector if opt.scale != 1.0 else None
-        c = model.project_conditioning(model.get_learned_conditioning(ref))
+        c = model.proj_out(model.get_learned_conditioning(ref))                      # scripts/inference.py:326-327
         z_inpaint = model.get_first_stage_encoding(model.encode_first_stage(test_model_kwargs["inpaint_image"]))
         test_model_kwargs["inpaint_image"] = z_inpaint
         test_model_kwargs["inpaint_mask"] = pipeline.resize_mask(test_model_kwargs["inpaint_mask"], z_inpaint.shape[-2:])

@@ -412,3 +412,27 @@ def test_every_tile_config_with_every_epilogue(dev, cfg):
         _close(got, ref, what=f"cfg {cfg}: fused GEGLU")
     finally:
         ops.tune(1, -1)
+
+
+def test_resize_bilinear_against_torch(dev):
+    """pbe_resize_bilinear_f32 (the mask resize of scripts/inference.py:332) against torch's F.interpolate on the CPU (fp32), both
+    antialias settings, the 512 -> 64 case of the path on a real bundled mask plus ragged / up-scaling sizes."""
+    import os
+    import numpy as np
+    from PIL import Image
+    import torch.nn.functional as F
+    here = os.path.dirname(os.path.abspath(__file__))
+    m = np.array(Image.open(os.path.join(here, "golden", "examples", "mask_example_1.png")).convert("L"))[None, None]
+    mask = torch.from_numpy((1 - m.astype(np.float32) / 255.0 >= 0.5).astype(np.float32))
+    g = torch.Generator().manual_seed(11)
+    cases_ = [(mask, (64, 64)), (torch.rand(2, 3, 224, 224, generator=g), (512, 512)), (torch.rand(3, 1, 100, 77, generator=g), (13, 31)),
+              (torch.rand(1, 2, 96, 96, generator=g), (96, 96)), (torch.rand(1, 1, 768, 768, generator=g), (96, 96))]
+    for x, size in cases_:
+        for aa in (True, False):
+            got = ops.resize_bilinear(x.to(dev), size, aa).cpu()
+            ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=aa)
+            assert got.shape == ref.shape
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-6, (tuple(x.shape), size, aa, err)
+    binary = ops.resize_bilinear(mask.to(dev), (64, 64), True).cpu()
+    assert 0.0 <= binary.min() and binary.max() <= 1.0 and ((binary > 0) & (binary < 1)).any()        # edges are NOT re-binarised (SURVEY.md §3.4)
