@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 4
+#define PBE_ABI_VERSION 5
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -79,7 +79,7 @@ typedef struct pbe_gemm_desc {
     int32_t bias_per_row;
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
-    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..8) | (split-K factor << 8), factor 0 = library's choice */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..9) | (split-K factor << 8), factor 0 = library's choice */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 /* Plan / workspace query for the SAME descriptor (nothing is launched): out6 = {tile config index, split-K factor,
@@ -96,7 +96,7 @@ int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* workspace_neede
  * Replaces Conv2d(k=3) dispatches in openaimodel.py:216,229-231 (ResBlock), :109-119 (Upsample:
  * F.interpolate + conv), :150-160 (Downsample s2 p1), :658-662,824-828 (conv in/out);
  * model.py:44-81,92-121 (VAE convs; Downsample pad (0,1,0,1) + s2 p0 == pad=0 here).
- * Requires C1 % 32 == 0 and C2 % 32 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
+ * Requires C1 % 64 == 0 and C2 % 64 == 0; small-Cin convs go through pbe_im2col3x3_f16 + GEMM.
  * Wp is the OIHW weight re-packed by the host to [Cout, 9*Cin] in (channel block, tap, channel) order — see kblock.
  * ------------------------------------------------------------------------------------------ */
 typedef struct pbe_conv3x3_desc {
@@ -114,8 +114,8 @@ typedef struct pbe_conv3x3_desc {
     void* workspace;        /* optional split-K scratch, as in pbe_gemm_desc */
     size_t workspace_bytes;
     int32_t tile_cfg;       /* -1 = heuristic, else tile config | (split-K factor << 8), as in pbe_gemm_desc */
-    int32_t kblock;         /* channel block cb of Wp's K order: k = ((ci/cb)*9 + tap)*cb + ci%cb; multiple of 32 that
-                               divides C1 and C2 (0 = 32).  A pixel's 9 taps are then re-read within 9*cb/32 k-tiles (L2 hits) */
+    int32_t kblock;         /* channel block cb of Wp's K order: k = ((ci/cb)*9 + tap)*cb + ci%cb; multiple of 64 that
+                               divides C1 and C2 (0 = 64).  A pixel's 9 taps are then re-read within 9*cb/64 k-tiles (L2 hits) */
 } pbe_conv3x3_desc;
 int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
 int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t* workspace_needed); /* as pbe_gemm_plan */
@@ -230,7 +230,7 @@ int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_
 
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
- * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the 8-wave tiles (0/1).
+ * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2).
  */
 int pbe_tune(int32_t key, int32_t value);
 

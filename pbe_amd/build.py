@@ -62,6 +62,27 @@ def _compile(src: str, extra) -> str:
     return obj
 
 
+def build_diagnostic(defines, out_path: str) -> str:
+    """A separate library with extra -D flags (e.g. PBE_STAMPS) for tools/: own object directory, never the shipped .so."""
+    obj_dir = out_path + ".obj"
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+
+    def one(src):
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(one, SOURCES))
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out_path], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return out_path
+
+
 def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     if force:
@@ -82,4 +103,7 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--stamps" in sys.argv:
+        print(build_diagnostic(["PBE_STAMPS"], os.path.join(HERE, "..", "tools", "_dbg", "libpbe_hip_stamps.so")))
+    else:
+        build(force="--force" in sys.argv, verbose=True)

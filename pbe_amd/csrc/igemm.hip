@@ -1,27 +1,26 @@
 // Implicit-GEMM on the gfx950 matrix cores: one kernel body, two activation loaders.
 //
 //   MODE 0 (dense)   C[m,n] = sum_k A[m,k] W[n,k]          Linear / 1x1 conv / bmm
-//   MODE 1 (conv3x3) m = (b,oy,ox), k = (ci/cb, tap, ci%cb) NHWC 3x3 conv gather, zero padding,
+//   MODE 1 (conv3x3) m = (b,oy,ox), k = (ci/cb, tap, ci%cb) NHWC 3x3 conv gather, zero padding, cb % 64 == 0,
 //                                                          optional fused nearest-2x upsample and
 //                                                          two-source channel concat
 //
 // Structure (CDNA4, wave64):
-//   * workgroup = NWM x NWN waves, block tile BM x BN x 32, each wave owns (BM/NWM) x (BN/NWN) as
-//     16x16 tiles of v_mfma_f32_16x16x32_f16.  The weights are the MFMA "A" operand and the
+//   * workgroup = NWM x NWN waves, block tile BM x BN x 64, each wave owns (BM/NWM) x (BN/NWN) as
+//     16x16 tiles of v_mfma_f32_16x16x32_f16 (two k-steps per k-tile).  The weights are the MFMA "A" operand and the
 //     activations the "B" operand, so an accumulator register quad holds 4 consecutive n for one m.
-//   * tiles stream global -> LDS with global_load_lds_dwordx4 (LDS-DMA, no staging registers)
-//     into a 4-slot ring: 3 k-tiles in flight per workgroup across ONE raw s_barrier per k-tile,
-//     retired with counted s_waitcnt vmcnt.  Measured: the kernel is bound by the per-CU LDS-DMA
-//     fill rate (~30 GB/s/CU from the Infinity Cache), so the block tile is as large as the
-//     problem allows (256x256 = 128 FLOP per staged byte) and small-M / deep-K problems are split
-//     along K over gridDim.z with a deterministic fp32 slab reduction.
-//   * LDS image: rows of 32 halfs (64 B = 4 chunks of 16 B).  An LDS-DMA instruction writes
-//     64 lanes x 16 B linearly, so the bank swizzle is applied to the per-lane SOURCE chunk
-//     (position p of row r holds global chunk p ^ f(r), f = {0,2,3,1}[(r>>2)&3]) and again on
-//     the fragment read: every ds_read_b128 of a 16x16x32 fragment is bank-conflict free.
+//   * tiles stream global -> LDS with global_load_lds_dwordx4 (LDS-DMA, no staging registers) into an S-slot ring
+//     (S = 2 or 3 by tile: S - 1 k-tiles in flight across ONE raw s_barrier per k-tile, retired with counted s_waitcnt vmcnt).
+//     A k-tile row is 64 halfs = 128 B = one whole cache line: a DMA instruction fetches 8 complete lines.  (Round 1 staged
+//     32 halfs per row; the half-line pieces capped the per-CU fill at 37 GB/s and the MFMA pipe sat idle for 55 % of the
+//     main loop - tools/phase_stamps.py, profiles/r02_phase_stamps_bk32.txt.)
+//   * LDS image: rows of 128 B = 8 chunks of 16 B.  An LDS-DMA instruction writes 64 lanes x 16 B linearly, so the bank
+//     swizzle is applied to the per-lane SOURCE chunk (position p of row r holds global chunk p ^ (r & 7)) and again on
+//     the fragment read: every ds_read_b128 of a 16x16x32 fragment is bank-conflict free in both k-steps.
 //     Out-of-range rows / taps / k read a 16-byte zero block (LDS-DMA cannot mask a lane).
 //   * workgroup ids are remapped so each XCD owns a contiguous run of tiles, n fastest: the
 //     weight panel and the activation rows a run touches stay in that XCD's L2.
+//   * small-M / deep-K problems are split along K over gridDim.z with a deterministic fp32 slab reduction.
 //   * epilogue: alpha, bias, row-broadcast vector, activation in fp32 registers -> fp16 C tile in
 //     LDS (one wave-row group at a time) -> whole 16-byte row segments to HBM, residual fused.
 #include <type_traits>
@@ -37,11 +36,28 @@ struct IGemmP {
     long sA, sW, sC, sR;
     float alpha; int act; int bias_row; int vec;
     // conv gather
-    int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 32)
+    int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 64)
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
+#ifdef PBE_STAMPS
+    unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 8 s_memtime stamps per workgroup
+#endif
 };
+
+// Diagnostic build (-DPBE_STAMPS, never the shipped library): wave 0 of every workgroup records s_memtime at its phase
+// boundaries into a buffer of its own; no output value depends on a stamp (cdna_hip_programming.md section 7, in-kernel stamps).
+#ifdef PBE_STAMPS
+#define PBE_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        if (p.stamps && threadIdx.x == 0) {                                                                            \
+            const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                     \
+            p.stamps[wg_ * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();      \
+        }                                                                                                              \
+    } while (0)
+#else
+#define PBE_STAMP(i) do { } while (0)
+#endif
 
 __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -52,29 +68,27 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4, bool PP = false>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
-    // PP (8-wave tiles only): "ping-pong" main loop.  Waves w and w + 4 share a SIMD; the two wave groups run the same
-    // [R: fragment reads + DMA issue | M: MFMAs] sequence offset by ONE barrier, so while one group's MFMAs own the
-    // SIMD's matrix pipe its partner's LDS reads, address arithmetic and LDS-DMA issue run in their shadow (without the
-    // stagger both waves of a SIMD read at the same time and then contend for the pipe: the read latency is exposed
-    // once per k-tile).  Two raw barriers per k-tile; see the hazard notes at the loop.
-    // S = LDS ring depth (4: three k-tiles in flight, one workgroup per CU for the big tiles; 2: one in flight, the
-    // smaller ring lets 2-4 workgroups share a CU so their prologues / epilogues overlap - shallow-K problems).
+    // S = LDS ring depth (S - 1 k-tiles of 64 in flight).  Sized per tile so the ring fills the LDS one workgroup (8-wave tiles)
+    // or two to three workgroups (4-wave tiles) can own on a CU.
+    // (A "ping-pong" form of the main loop for the 8-wave tiles - wave groups 0-3 / 4-7 offset by one barrier, [fragment reads +
+    //  DMA issue | MFMAs] with two barriers per k-tile - was built and measured on every conv / GEMM shape of the path: bit-identical
+    //  output, 7 % slower on the conv class (780.9 -> 724.0 TFLOP/s), 2 % slower on the GEMM class.  profiles/r02_ab_pingpong_rejected.txt.)
     constexpr int NW = NWM * NWN, NT = NW * 64;
     constexpr int D = S - 1;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
-    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
-    constexpr int PW = BN / 16;                       // 16-row DMA pieces of the weight tile, dealt round-robin to the waves
-    constexpr int LA = BM / 16 / NW, LW = (PW + NW - 1) / NW, LPT = LA + LW;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int PA = BM / 8, PW = BN / 8;           // 8-row x 128-byte DMA pieces (1 KiB = one wave instruction)
+    constexpr int LA = PA / NW, LW = PW / NW, LPT = LA + LW;
     constexpr int CLD = BN + 8;
-    static_assert(LA >= 1 && BM % (16 * NW) == 0 && BN % 16 == 0, "activation pieces must divide over the waves");
-    // When PW is not a multiple of NW (BN = 320, 8 waves) the waves left without a piece issue a dummy DMA of
-    // the zero block into a 1-KiB dump slot, so every wave's vmcnt stays uniform (LPT loads per k-tile).
+    static_assert(S >= 2 && S <= 4 && PA % NW == 0 && PW % NW == 0 && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % NWM, wn = wave / NWM;
+    PBE_STAMP(0);                                    // workgroup start
+    PBE_STAMP(7);                                    // wall clock (100 MHz) of the start
     int tile;
     {   // XCD-aware tile order (bijective for any grid size)
         const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -84,9 +98,15 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const long bz = blockIdx.y;
 
-    // ---- loader state: this lane's row inside a 16-row DMA piece and its source chunk ----
-    const int lrow = lane >> 2;
-    const int gch = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);
+    // ---- loader state: this lane's row inside an 8-row DMA piece and its source chunk ----
+    // LDS rows are 128 B (64 halfs = 8 chunks of 16 B) = one whole cache line per row: a wave's DMA instruction fetches 8
+    // complete lines (64-byte row pieces - the BK = 32 layout of round 1 - filled at 37 GB/s per CU in the real kernel,
+    // tools/phase_stamps.py: 1 440 cycles per k-tile of a 128x320 tile against 640 cycles of MFMA work).
+    // LDS-DMA writes lane l at base + 16 l, so the bank swizzle goes on the SOURCE chunk: position p of row r holds global
+    // chunk p ^ (r & 7); the fragment read applies the same XOR (conflict-free ds_read_b128 for both k-steps, checked by
+    // enumeration over the hardware's 16-lane service groups).
+    const int lrow = lane >> 3;
+    const int gch = (lane & 7) ^ lrow;
     const h16* zsrc = reinterpret_cast<const h16*>(g_pbe_zero16);
 
     bool a_ok[LA];
@@ -94,35 +114,20 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const h16* a_row2[LA];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int m = m0 + (wave * LA + i) * 16 + lrow;
+        const int m = m0 + (wave * LA + i) * 8 + lrow;
         a_ok[i] = m < p.M;
         a_row[i] = p.A + bz * p.sA + (long)m * p.lda;
         a_row2[i] = p.A2 ? p.A2 + (long)m * p.lda2 : p.A;
     }
-    // conv: K is ordered (channel block of 32, tap, channel) so the 9 taps of a pixel's 32 channels are
-    // consecutive k-tiles — the shifted re-reads hit L2 instead of going back to the Infinity Cache / HBM
-    // (measured: tap-major order re-fetched the input 9x beyond L2).  The tap -> input-pixel map of this
-    // tile's BM rows is built once into LDS: tab[tap][row] = pixel index, or -1 outside the (virtual) image.
+    // conv: K is ordered (channel block cb, tap, channel) so the 9 taps of a pixel's cb channels are consecutive k-tiles -
+    // the shifted re-reads hit L2 instead of going back to the Infinity Cache / HBM (measured: tap-major order re-fetched the
+    // input 9x beyond L2).  The tap -> input-pixel map of this tile's BM rows is built once into LDS:
+    // tab[tap][row] = pixel index, or -1 outside the (virtual) image.
     int* tab = reinterpret_cast<int*>(smem + S * STAGE);
-    unsigned char* dump = smem + S * STAGE + (MODE == 1 ? 9 * BM * 4 : 0);
-    // Epilogue vectors of this tile, staged ONCE at kernel start (their global latency hides under the whole main loop;
-    // fetched inside the epilogue they cost one exposed round trip per 16 output columns - measured 35 % of a K = 320 GEMM):
+    // Epilogue vectors of this tile, staged ONCE (their global latency hides under the first DMA tile):
     // svec[s][c] = bias[n0 + c] + rowvec[first sample of the tile + s][n0 + c], up to 4 samples per tile.
-    float* svec = reinterpret_cast<float*>(smem + (S * STAGE > WM * CLD * 2 ? S * STAGE : WM * CLD * 2) + (MODE == 1 ? 9 * BM * 4 : 0) +
-                                           ((PW % NW) ? 1024 : 0));
+    float* svec = reinterpret_cast<float*>(smem + (S * STAGE > WM * CLD * 2 ? S * STAGE : WM * CLD * 2) + (MODE == 1 ? 9 * BM * 4 : 0));
     const int sv_ns = (p.rowvec && p.group_rows < BM) ? BM / p.group_rows : 1;       // samples per tile (tile is sample-aligned when sv_ok)
-    if (p.sv_ok && p.splits <= 1) {
-        const int s0 = p.rowvec ? m0 / p.group_rows : 0;
-        for (int idx = tid; idx < sv_ns * BN; idx += NT) {
-            const int si = idx / BN, c = idx - si * BN, n = n0 + c;
-            float v = 0.f;
-            if (n < p.N) {
-                if (p.bias && !p.bias_row) v = p.bias[n];
-                if (p.rowvec && (long)(s0 + si) * p.group_rows < p.M) v += (float)p.rowvec[(long)(s0 + si) * p.ldv + n];
-            }
-            svec[si * BN + c] = v;
-        }
-    }
     if (MODE == 1) {
         const int hw = p.Ho * p.Wo, Hv = p.H << p.ups, Wv = p.Wd << p.ups;
         for (int row = tid; row < BM; row += NT) {            // one thread per tile row: one (b, oy, ox) decode, 9 taps
@@ -144,12 +149,11 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const h16* w_row[LW];
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-        const int pc = wave + NW * i;
-        const int n = n0 + pc * 16 + lrow;
-        w_ok[i] = pc < PW && n < p.N;
+        const int n = n0 + (wave + NW * i) * 8 + lrow;
+        w_ok[i] = n < p.N;
         w_row[i] = p.W + bz * p.sW + (long)(w_ok[i] ? n : 0) * p.ldw;
     }
-    const int nk_all = (p.K + 31) >> 5;
+    const int nk_all = (p.K + 63) >> 6;
     int kt0 = 0, nk = nk_all;                        // this workgroup's k-tile range [kt0, nk)
     if (p.splits > 1) {
         const int per = (nk_all + p.splits - 1) / p.splits;
@@ -157,21 +161,21 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         nk = min(nk_all, kt0 + per);
     }
     // conv K order: (channel block of cb, tap, channel): state of the NEXT k-tile to issue
-    const int KB = MODE == 1 ? p.cb >> 5 : 1;        // k-tiles per (block, tap) visit
+    const int KB = MODE == 1 ? p.cb >> 6 : 1;        // k-tiles per (block, tap) visit
     int tap = 0, c0 = 0, kj = 0;
     if (MODE == 1 && kt0 > 0) {
         const int per_blk = 9 * KB, cblk = kt0 / per_blk, r = kt0 - cblk * per_blk;
-        tap = r / KB; kj = r - tap * KB; c0 = cblk * p.cb + kj * 32;
+        tap = r / KB; kj = r - tap * KB; c0 = cblk * p.cb + kj * 64;
     }
     const h16* a_src[LA];
     bool fresh = true;
 #pragma unroll
     for (int i = 0; i < LA; ++i) a_src[i] = zsrc;
 
-    auto issue = [&](int kt) {
-        unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
+    auto issue = [&](int kt, int slot) {
+        unsigned char* sa = smem + slot * STAGE;
         unsigned char* sw = sa + A_BYTES;
-        const int k = kt * 32 + gch * 8;
+        const int k = kt * 64 + gch * 8;
         const bool kok = k < p.K;
         if (MODE == 0) {
 #pragma unroll
@@ -181,23 +185,23 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
             }
         } else {
-            if (kj == 0 || fresh) {                   // new (block, tap): look the pixels up; otherwise +32 channels
+            if (kj == 0 || fresh) {                   // new (block, tap): look the pixels up; otherwise +64 channels
                 fresh = false;
                 const bool first = c0 < p.C1;         // which concat source this channel block lives in (uniform)
                 const h16* base = first ? p.A + c0 + gch * 8 : p.A2 + (c0 - p.C1) + gch * 8;
                 const long cs = first ? p.C1 : p.C2;
 #pragma unroll
                 for (int i = 0; i < LA; ++i) {
-                    const int pix = tab[tap * BM + (wave * LA + i) * 16 + lrow];
+                    const int pix = tab[tap * BM + (wave * LA + i) * 8 + lrow];
                     a_src[i] = pix >= 0 ? base + (long)pix * cs : nullptr;
                 }
             }
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 PBE_GLDS16(a_src[i] ? a_src[i] : zsrc, sa + (wave * LA + i) * 1024);
-                if (a_src[i]) a_src[i] += 32;
+                if (a_src[i]) a_src[i] += 64;
             }
-            c0 += 32;
+            c0 += 64;
             if (++kj == KB) {
                 kj = 0;
                 if (++tap == 9) tap = 0; else c0 -= p.cb;      // next tap of the same block, or first tap of the next block
@@ -206,8 +210,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
 #pragma unroll
         for (int i = 0; i < LW; ++i) {
             const h16* src = (w_ok[i] && kok) ? w_row[i] + k : zsrc;
-            const int pc = wave + NW * i;
-            PBE_GLDS16(src, (PW % NW == 0 || pc < PW) ? sw + pc * 1024 : dump);
+            PBE_GLDS16(src, sw + (wave + NW * i) * 1024);
         }
     };
 
@@ -218,87 +221,77 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
-    const int rsw = (fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
-    const int a_rd = (wm * WM + fr) * 64 + rsw, w_rd = (wn * WN + fr) * 64 + rsw;
+    const int rsw = (fq ^ (fr & 7)) << 4;             // byte offset of k-step 0's chunk; k-step 1 is rsw ^ 64
+    const int a_rd = (wm * WM + fr) * 128, w_rd = (wn * WN + fr) * 128;
 
+    PBE_STAMP(1);                                    // loader state (+ tap table) ready
 #pragma unroll
     for (int t = 0; t < D; ++t)
-        if (kt0 + t < nk) issue(kt0 + t);
+        if (kt0 + t < nk) issue(kt0 + t, t);
+    PBE_STAMP(2);                                    // ring primed (issue only)
+    if (p.sv_ok && p.splits <= 1) {                  // staged AFTER the first DMAs are in flight: both latencies overlap
+        const int s0 = p.rowvec ? m0 / p.group_rows : 0;
+        for (int idx = tid; idx < sv_ns * BN; idx += NT) {
+            const int si = idx / BN, c = idx - si * BN, n = n0 + c;
+            float v = 0.f;
+            if (n < p.N) {
+                if (p.bias && !p.bias_row) v = p.bias[n];
+                if (p.rowvec && (long)(s0 + si) * p.group_rows < p.M) v += (float)p.rowvec[(long)(s0 + si) * p.ldv + n];
+            }
+            svec[si * BN + c] = v;
+        }
+    }
 
-    if constexpr (!PP) {
+    // Tiles with few accumulators fetch BOTH k-steps' fragments before the first MFMA (the second set's LDS latency hides
+    // under the first set's MFMAs); the 256-row tiles have no registers for that and read k-step 1 after issuing k-step 0.
+    constexpr bool BOTH = TM * TN * 4 + 2 * (TM + TN) * 4 <= 176;
+    int slot_rd = 0, slot_wr = D % S;
     for (int kt = kt0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;                 // tiles issued after tile kt that may stay in flight
-        if (rem >= D - 1) wait_vmcnt<(D - 1) * LPT>();
-        else if (rem == 1) wait_vmcnt<LPT>();
+#ifdef PBE_STAMPS
+        if (kt == kt0 + 1) PBE_STAMP(3);             // first k-tile consumed: prologue latency ends
+#endif
+        const int rem = min(nk - 1 - kt, D - 1);     // later tiles that may stay in flight
+        if (D >= 3 && rem >= 2) wait_vmcnt<2 * LPT>();
+        else if (D >= 2 && rem >= 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot (kt-1)%S is free
-        const unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
+        __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot_wr (tile kt-1's) is free
+        const unsigned char* sa = smem + slot_rd * STAGE;
         const unsigned char* sw = sa + A_BYTES;
-        h16x8 fa[TM], fw[TN];
+        h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 64);
+        for (int ks = 0; ks < (BOTH ? 2 : 1); ++ks) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 64);
+            for (int j = 0; j < TM; ++j) fa[ks][j] = *reinterpret_cast<const h16x8*>(sa + a_rd + (rsw ^ (ks * 64)) + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
+        }
         __builtin_amdgcn_sched_barrier(0);           // fragment reads go out first; the DMA address math runs in their shadow
-        if (kt + D < nk) issue(kt + D);
+        if (kt + D < nk) issue(kt + D, slot_wr);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+        if constexpr (!BOTH) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fa[0][j] = *reinterpret_cast<const h16x8*>(sa + a_rd + (rsw ^ 64) + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ 64) + i * 16 * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-    }
-    } else {
-        static_assert(!PP || (NW == 8 && S == 4), "ping-pong needs two waves per SIMD and the 4-slot ring");
-        // Barriers b0, b1, ... as group 0 (waves 0-3) counts them: group 0 runs R(kt) | b(2i) | M(kt) | b(2i+1), group 1
-        // (waves 4-7) passes one extra barrier first and therefore runs R(kt) between b(2i) and b(2i+1).
-        //   RAW: a wave retires its own DMAs of tile kt+1 (counted vmcnt) at the END of R(kt), i.e. before b(2i) / b(2i+1);
-        //        tile kt+1 is first read by group 0 after b(2i+1) - one barrier after every wave's wait.
-        //   WAR: DMA(kt+3) overwrites slot (kt-1) % 4.  Its last readers (group 1, R(kt-1)) complete their reads
-        //        (lgkmcnt(0)) before b(2i-1); the earliest issue (group 0, R(kt)) comes after b(2i-1).
-        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-        if (kt0 < nk) {
-            const int rem0 = nk - 1 - kt0;
-            if (rem0 >= D - 1) wait_vmcnt<(D - 1) * LPT>();
-            else if (rem0 == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                // tile kt0 landed for every wave
-        if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
-        for (int kt = kt0; kt < nk; ++kt) {
-            const unsigned char* sa = smem + (kt & (S - 1)) * STAGE;
-            const unsigned char* sw = sa + A_BYTES;
-            h16x8 fa[TM], fw[TN];
-#pragma unroll
-            for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const h16x8*>(sa + a_rd + j * 16 * 64);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + i * 16 * 64);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + D < nk) issue(kt + D);
-            const int rem = nk - 2 - kt;             // tiles issued after tile kt+1 that may stay in flight
-            if (rem >= D - 1) wait_vmcnt<(D - 1) * LPT>();
-            else if (rem == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();            // end of R: my fragments are in registers, my share of tile kt+1 landed
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();            // end of M
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last M phase
+        slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+        slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PBE_STAMP(4);                                    // main loop issued
 
     if (p.splits > 1) {
         // raw fp32 partial sums -> slab blockIdx.z; splitk_reduce_kernel applies the epilogue
@@ -312,6 +305,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = acc[i][j];
             }
         }
+        PBE_STAMP(6);
         return;
     }
 
@@ -389,31 +383,58 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             }
         }
     };
-    // LDS -> global half: whole 16-byte row segments, residual added on the way out
+    // LDS -> global half: whole 16-byte row segments, residual added on the way out.  A thread's chunks are handled in batches
+    // of UB: all residual loads of a batch are issued first, then the LDS reads, then the adds and stores - one exposed memory
+    // round trip per batch instead of one per chunk (tools/phase_stamps.py: the chunk-at-a-time form spent 11 400 of a
+    // K = 320 GEMM workgroup's 33 800 cycles here when a residual is fused, 4 000 without).
     auto copy_out = [&](int g, auto GG) {
         constexpr bool gg = decltype(GG)::value;             // GEGLU halves the output width
         constexpr int cpr = gg ? CPR / 2 : CPR;
+        constexpr int TOT = GR * cpr, IT = (TOT + NT - 1) / NT;
+        // (tiles whose accumulators stay live across the passes - NG > 1 - have no registers for a deep batch)
+        constexpr int UB = !ONE_PASS ? (IT % 2 == 0 ? 2 : 1) : (IT % 5 == 0 ? 5 : (IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : (IT % 2 == 0 ? 2 : 1))));
         const int Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
-        for (int idx = tid; idx < GR * cpr; idx += NT) {
+        if (p.vec) {
+            for (int it0 = 0; it0 < IT; it0 += UB) {
+                h16x8 v[UB], r[UB];
+                long go[UB];
+                int lo[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int idx = tid + (it0 + u) * NT;
+                    const int row = idx / cpr, ch = idx - row * cpr;
+                    const int m = m0 + g * GR + row, n = nb + ch * 8;
+                    const bool ok = idx < TOT && m < p.M && n < Nout;
+                    go[u] = ok ? (long)m * p.ldc + n : -1;
+                    lo[u] = row * CLD + ch * 8;
+                    if (ok && Rb) r[u] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (go[u] >= 0) v[u] = *reinterpret_cast<const h16x8*>(sC + lo[u]);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (go[u] < 0) continue;
+                    if (Rb) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[u][e] = (h16)((float)v[u][e] + (float)r[u][e]);
+                    }
+                    *reinterpret_cast<h16x8*>(Cb + go[u]) = v[u];
+                }
+            }
+            return;
+        }
+        for (int idx = tid; idx < TOT; idx += NT) {
             const int row = idx / cpr, ch = idx - row * cpr;
             const int m = m0 + g * GR + row, n = nb + ch * 8;
             if (m >= p.M || n >= Nout) continue;
-            h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
-            if (p.vec) {
-                if (Rb) {
-                    const h16x8 r = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+            const h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r[e]);
-                }
-                *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (n + e < Nout) {
-                        float f = (float)v[e];
-                        if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
-                        Cb[(long)m * p.ldc + n + e] = (h16)f;
-                    }
+            for (int e = 0; e < 8; ++e) {
+                if (n + e < Nout) {
+                    float f = (float)v[e];
+                    if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
+                    Cb[(long)m * p.ldc + n + e] = (h16)f;
                 }
             }
         }
@@ -440,9 +461,13 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             else run(std::false_type{});
         }
         __syncthreads();
+#ifdef PBE_STAMPS
+        if (g == NG - 1) PBE_STAMP(5);               // last register -> LDS pass done (includes waiting for the MFMAs to drain)
+#endif
         if (p.act == PBE_ACT_GEGLU) copy_out(g, std::true_type{});
         else copy_out(g, std::false_type{});
     }
+    PBE_STAMP(6);                                    // stores issued
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue: 4 columns per thread.
@@ -498,26 +523,35 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 struct Plan { int cfg; int splits; };
 struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
-// eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP)
+// eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP).
+// Ring depth per tile (k-tiles of 64): the deepest that fits the LDS share of the tile's workgroups per CU.
 static const TileCfg kCfg[] = {
-    {256, 256, 2, 4, 1, 1.00}, {256, 128, 4, 2, 1, 0.82}, {128, 256, 2, 4, 1, 0.75},
-    {128, 128, 2, 2, 2, 0.88}, {128, 64, 2, 2, 2, 0.65}, {64, 128, 2, 2, 2, 0.65}, {64, 64, 2, 2, 2, 0.60},
-    {256, 320, 2, 4, 1, 1.05},           // N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
-    {128, 320, 2, 4, 1, 0.96}};          // same, half the rows: fills the chip when M / 256 < 256 tiles
-// (Ring depth 2 variants of the 128-row tiles - 2-4 workgroups per CU - were measured for every shape of the path,
-//  profiles/r01_autotune_report.txt round "S2": 20-30 % slower than depth 4 on the shallow-K GEMMs they were meant for.)
+    {256, 256, 2, 4, 1, 1.00},           // 0: S = 2, 128 KiB
+    {256, 128, 4, 2, 1, 0.82},           // 1: S = 3, 144 KiB
+    {128, 256, 2, 4, 1, 0.75},           // 2: S = 3, 144 KiB
+    {128, 128, 2, 2, 2, 0.88},           // 3: S = 2,  64 KiB, 4 waves: two workgroups per CU
+    {128, 64, 2, 2, 3, 0.65},            // 4: S = 2,  48 KiB
+    {64, 128, 2, 2, 3, 0.65},            // 5: S = 2,  48 KiB
+    {64, 64, 2, 2, 4, 0.60},             // 6: S = 2,  32 KiB
+    {256, 320, 2, 4, 1, 1.05},           // 7: S = 2, 144 KiB: N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
+    {128, 320, 2, 4, 1, 0.96},           // 8: S = 2, 112 KiB: same, half the rows: fills the chip when M / 256 < 256 tiles
+    {128, 160, 2, 2, 2, 0.90}};          // 9: S = 2,  72 KiB, 4 waves: two workgroups per CU overlap each other's prologue / epilogue
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
+#ifdef PBE_STAMPS
+unsigned long long* g_pbe_stamps = nullptr;
+extern "C" int pbe_debug_set_stamps(void* buf) { g_pbe_stamps = (unsigned long long*)buf; return PBE_OK; }
+#endif
 int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index [| splits << 8]) forces a tile config (and split-K factor); -1 = heuristic
 int g_pbe_allow_splitk = 1;      // pbe_tune(2, 0/1)
 
 static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_bytes, long tiles) {
     if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) return 1;
-    const int nk = (p.K + 31) >> 5;
+    const int nk = (p.K + 63) >> 6;                          // k-tiles of 64
     const long slots = 256L * c.slots_per_cu;
-    if (tiles * 4 > slots * 3 || nk < 16) return 1;          // grid already fills >= 75 % of the chip
+    if (tiles * 4 > slots * 3 || nk < 8) return 1;           // grid already fills >= 75 % of the chip
     int s = (int)((slots * 5 / 4 + tiles - 1) / tiles);
-    if (s > nk / 8) s = nk / 8;
+    if (s > nk / 4) s = nk / 4;
     if (s > 32) s = 32;
     while (s > 1 && (size_t)s * p.M * p.N * sizeof(float) > ws_bytes) --s;
     if (s < 2) return 1;
@@ -529,17 +563,17 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
-static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95};
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97};
 
 // want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
-// A requested factor is clamped to what the problem allows (batch 1, >= 8 k-tiles per slice, slabs fit the workspace).
+// A requested factor is clamped to what the problem allows (batch 1, >= 4 k-tiles of 64 per slice, slabs fit the workspace).
 static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg) {
     Plan best{3, 1};
     double best_score = -1.0;
     const int want = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : want_cfg;
     const int forced = (want >= 0 && (want & 255) < kNCfg) ? (want & 255) : -1;
     const int want_splits = want >= 0 ? (want >> 8) & 255 : 0;
-    const bool shallow = ((p.K + 31) >> 5) < 20;
+    const bool shallow = ((p.K + 63) >> 6) < 10;
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];
@@ -548,10 +582,10 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
         const long tiles = tm * tn * batch;
         int sp = splits_for(p, t, batch, ws_bytes, tiles);
         if (forced >= 0 && want_splits > 0) {
-            const int nk = (p.K + 31) >> 5;
+            const int nk = (p.K + 63) >> 6;
             sp = want_splits;
             if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) sp = 1;
-            if (sp > nk / 8) sp = nk / 8;
+            if (sp > nk / 4) sp = nk / 4;
             while (sp > 1 && (size_t)sp * p.M * p.N * sizeof(float) > ws_bytes) --sp;
             if (sp < 2) sp = 1;
             else { const int per = (nk + sp - 1) / sp; sp = (nk + per - 1) / per; }
@@ -567,26 +601,20 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     return best;
 }
 
-int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): staggered two-group main loop for the 8-wave tiles
-
-template <int BM, int BN, int NWM, int NWN, int MODE, int S = 4, bool PP = false>
+template <int BM, int BN, int NWM, int NWN, int S, int MODE>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
-    if constexpr (!PP && NWM * NWN == 8 && S == 4) {
-        if (g_pbe_pingpong) { launch_cfg<BM, BN, NWM, NWN, MODE, S, true>(p, batch, s); return; }
-    }
-    constexpr size_t ring = S * (BM + BN) * 64;
+    constexpr size_t ring = (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + ((BN / 16) % (NWM * NWN) ? 1024 : 0) +
-                           4 * BN * sizeof(float);                                      // + svec[NSV = 4][BN]
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float);   // + svec[4][BN]
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, PP>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     pbe_prof_begin(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, PP>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch);
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
@@ -600,16 +628,20 @@ template <int MODE>
 static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int want_cfg) {
     const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg);
     p.splits = pl.splits;
+#ifdef PBE_STAMPS
+    p.stamps = g_pbe_stamps;
+#endif
     switch (pl.cfg) {
-        case 0: launch_cfg<256, 256, 2, 4, MODE>(p, batch, s); break;
-        case 1: launch_cfg<256, 128, 4, 2, MODE>(p, batch, s); break;
-        case 2: launch_cfg<128, 256, 2, 4, MODE>(p, batch, s); break;
-        case 3: launch_cfg<128, 128, 2, 2, MODE>(p, batch, s); break;
-        case 4: launch_cfg<128, 64, 2, 2, MODE>(p, batch, s); break;
-        case 5: launch_cfg<64, 128, 2, 2, MODE>(p, batch, s); break;
-        case 7: launch_cfg<256, 320, 2, 4, MODE>(p, batch, s); break;
-        case 8: launch_cfg<128, 320, 2, 4, MODE>(p, batch, s); break;
-        default: launch_cfg<64, 64, 2, 2, MODE>(p, batch, s); break;
+        case 0: launch_cfg<256, 256, 2, 4, 2, MODE>(p, batch, s); break;
+        case 1: launch_cfg<256, 128, 4, 2, 3, MODE>(p, batch, s); break;
+        case 2: launch_cfg<128, 256, 2, 4, 3, MODE>(p, batch, s); break;
+        case 3: launch_cfg<128, 128, 2, 2, 2, MODE>(p, batch, s); break;
+        case 4: launch_cfg<128, 64, 2, 2, 2, MODE>(p, batch, s); break;
+        case 5: launch_cfg<64, 128, 2, 2, 2, MODE>(p, batch, s); break;
+        case 7: launch_cfg<256, 320, 2, 4, 2, MODE>(p, batch, s); break;
+        case 8: launch_cfg<128, 320, 2, 4, 2, MODE>(p, batch, s); break;
+        case 9: launch_cfg<128, 160, 2, 2, 2, MODE>(p, batch, s); break;
+        default: launch_cfg<64, 64, 2, 2, 2, MODE>(p, batch, s); break;
     }
 }
 
@@ -617,7 +649,6 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 1) { g_pbe_force_cfg = (value >= 0 && (value & 255) < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
-    if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
@@ -684,7 +715,7 @@ static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
     PBE_REQUIRE(d && d->X && d->Wp && d->Y, "%s: null operand", who);
     const int Cin = d->C1 + d->C2;
     PBE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: bad dims", who);
-    PBE_REQUIRE(d->C1 > 0 && d->C1 % 32 == 0 && d->C2 >= 0 && d->C2 % 32 == 0, "%s: C1=%d C2=%d must be multiples of 32 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", who, d->C1, d->C2);
+    PBE_REQUIRE(d->C1 > 0 && d->C1 % 64 == 0 && d->C2 >= 0 && d->C2 % 64 == 0, "%s: C1=%d C2=%d must be multiples of 64 (use pbe_im2col3x3_f16 + pbe_gemm_f16 for small Cin)", who, d->C1, d->C2);
     PBE_REQUIRE((d->C2 == 0) == (d->X2 == nullptr), "%s: X2 / C2 mismatch", who);
     PBE_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2", who);
     PBE_REQUIRE(d->pad == 0 || d->pad == 1, "%s: pad must be 0 or 1", who);
@@ -707,8 +738,8 @@ static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
     p.vec = (d->Cout % 8 == 0) && (!d->resid || al16(d->resid));
     p.H = d->H; p.Wd = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Ho = Ho; p.Wo = Wo;
     p.cstride = d->stride; p.pad = d->pad; p.ups = d->upsample;
-    p.cb = d->kblock > 0 ? d->kblock : 32;
-    PBE_REQUIRE(p.cb % 32 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "%s: kblock=%d must be a multiple of 32 dividing C1=%d and C2=%d", who, p.cb, d->C1, d->C2);
+    p.cb = d->kblock > 0 ? d->kblock : 64;
+    PBE_REQUIRE(p.cb % 64 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "%s: kblock=%d must be a multiple of 64 dividing C1=%d and C2=%d", who, p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
     return PBE_OK;
 }

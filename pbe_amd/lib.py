@@ -7,8 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbe_hip.so")
-ABI_VERSION = 4
+LIB_PATH = os.environ.get("PBE_LIB_PATH") or os.path.join(_HERE, "libpbe_hip.so")     # PBE_LIB_PATH: diagnostic builds (tools/) only
+ABI_VERSION = 5
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -119,7 +119,7 @@ def load() -> C.CDLL:
         if v != ABI_VERSION:
             raise PbeError(f"libpbe_hip.so ABI version {v} != expected {ABI_VERSION}")
         built, want = lib.pbe_source_hash().decode(), source_hash()
-        if built != want and not os.environ.get("PBE_ALLOW_STALE_LIB"):
+        if built != want and not os.environ.get("PBE_LIB_PATH"):
             raise PbeError(f"libpbe_hip.so was built from other sources (binary {built}, tree {want}): run `python -m pbe_amd.build`")
         _lib = lib
     return _lib

@@ -466,9 +466,9 @@ def bcast_row(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, B: int, y_bs:
 # ---- weight packing (one-off, at load time) ---------------------------------------------------
 def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """OIHW fp32 -> packed fp16 [Cout, 9*Cin] in the K order the kernels gather in.
-    * cin_pad is None (Cin % 32 == 0, implicit-GEMM conv): k = ((ci // cb) * 9 + ky*3+kx) * cb + ci % cb with
-      cb = conv_kblock(Cin) — channel-block major, tap minor, so a pixel's 9 shifted reads stay within 9*cb/32
-      k-tiles of each other (L2 reuse) while cb/32 consecutive k-tiles walk the same pixel (+32 channels).
+    * cin_pad is None (Cin % 64 == 0, implicit-GEMM conv): k = ((ci // cb) * 9 + ky*3+kx) * cb + ci % cb with
+      cb = conv_kblock(Cin) — channel-block major, tap minor, so a pixel's 9 shifted reads stay within 9*cb/64
+      k-tiles of each other (L2 reuse) while cb/64 consecutive k-tiles walk the same pixel (+64 channels).
     * cin_pad given (tiny Cin, im2col + GEMM path): k = (ky*3+kx) * cin_pad + ci, zero-padded channels."""
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
@@ -477,7 +477,7 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional
         if cin_pad != ci:
             wp = torch.nn.functional.pad(wp, (0, cin_pad - ci))
         return wp.reshape(co, -1).to(torch.float16).contiguous()
-    assert ci % 32 == 0, "implicit-GEMM conv needs Cin % 32 == 0 (use cin_pad for the im2col path)"
+    assert ci % 64 == 0, "implicit-GEMM conv needs Cin % 64 == 0 (use cin_pad for the im2col path)"
     cb = conv_kblock(*(split if split else (ci, 0)))       # split = (C1, C2) when the conv reads a channel concat
     assert not split or sum(split) == ci
     wp = wp.reshape(co, 9, ci // cb, cb).permute(0, 2, 1, 3)      # [Co, Ci/cb, 9, cb]
@@ -486,11 +486,12 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional
 
 def conv_kblock(c1: int, c2: int = 0) -> int:
     """Channel block of the conv K order for a layer whose input is c1 (+ c2 concatenated) channels
-    (deterministic, shared by pack_conv3x3 and conv3x3): the largest of 160 / 128 / 64 / 32 dividing both."""
-    for cb in (160, 128, 64, 32):
-        if c1 % cb == 0 and c2 % cb == 0:
+    (deterministic, shared by pack_conv3x3 and conv3x3): the largest of 320 / 256 / 128 / 64 dividing both (the kernel walks K in
+    tiles of 64 channels; a block's 9 taps are 9 * cb / 64 consecutive k-tiles, so a pixel's shifted re-reads stay L2 hits)."""
+    for cb in (320, 256, 128, 64):
+        if c1 % cb == 0 and (c2 == 0 or c2 % cb == 0):
             return cb
-    raise _l.PbeError(f"conv: C1={c1} / C2={c2} are not multiples of 32")
+    raise _l.PbeError(f"conv: C1={c1} / C2={c2} are not multiples of 64")
 
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:

@@ -420,7 +420,7 @@ def test_resize_bilinear_against_torch(dev):
     import os
     import numpy as np
     from PIL import Image
-    import torch.nn.functional as F
+    from pbe_amd import ops
     here = os.path.dirname(os.path.abspath(__file__))
     m = np.array(Image.open(os.path.join(here, "golden", "examples", "mask_example_1.png")).convert("L"))[None, None]
     mask = torch.from_numpy((1 - m.astype(np.float32) / 255.0 >= 0.5).astype(np.float32))

@@ -24,7 +24,7 @@ import torch  # noqa: E402
 from pbe_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-NCFG = 9
+NCFG = 10
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32)
 
 
@@ -108,12 +108,12 @@ def main():
             order = sorted(range(NCFG), key=lambda c: times[c + 1])
             best, best_t = order[0], times[order[0] + 1]
             f = key.split(":")
-            nk = (int(f[3]) if f[0] == "g" else 9 * (int(f[4]) + int(f[5]))) // 32
+            nk = (int(f[3]) if f[0] == "g" else 9 * (int(f[4]) + int(f[5]))) // 64
             split_note = ""
-            if (f[0] == "c" or int(f[4]) == 1) and nk >= 16:                     # split-K exists for batch-1 problems with >= 16 k-tiles
-                for cfg in order[:6]:
+            if (f[0] == "c" or int(f[4]) == 1) and nk >= 8:                      # split-K exists for batch-1 problems with >= 8 k-tiles of 64
+                for cfg in order[:5]:
                     for sp in SPLITS:
-                        if sp > nk // 8:
+                        if sp > nk // 4:
                             break
                         ops.tune(1, cfg | (sp << 8))
                         t = timeit(call, iters)

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of igemm_kernel spend its cycles?  (diagnostic build, cdna_hip_programming.md section 7 "in-kernel stamps")
+
+Builds / loads tools/_dbg/libpbe_hip_stamps.so (python -m pbe_amd.build --stamps: the shipped sources with -DPBE_STAMPS), runs one
+GEMM / conv shape of the path and prints, over all workgroups, the median / p10 / p90 cycles of each phase:
+
+    setup      kernel entry -> loader state, tap table (conv), epilogue vectors staged
+    prime      issue of the first D k-tiles' LDS-DMAs
+    first      until the first k-tile has been consumed (prologue latency: first DMA landing)
+    mainloop   remaining k-tiles
+    stage      accumulators -> epilogue math -> LDS (includes the MFMA drain)
+    copyout    LDS -> global stores (residual add)
+
+    PBE_LIB_PATH is set by this script; never use the stamps build for timing claims (stamps cost ~11 % wave cycles).
+    python tools/phase_stamps.py g:32768:2560:320:geglu  g:32768:320:320:resid  c:8:64:64:320:0:320  ...
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["PBE_LIB_PATH"] = os.path.join(ROOT, "tools", "_dbg", "libpbe_hip_stamps.so")
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pbe_amd import lib, ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+NAMES = ["setup", "prime", "first", "mainloop", "stage", "copyout"]
+
+
+def rnd(*shape):
+    return (torch.randn(*shape, device=dev) * 0.5).half()
+
+
+def make(spec):
+    f = spec.split(":")
+    if f[0] == "g":
+        M, N, K = int(f[1]), int(f[2]), int(f[3])
+        kind = f[4] if len(f) > 4 else ""
+        a, w, bias = rnd(M, K), rnd(N, K), torch.randn(N, device=dev)
+        resid = rnd(M, N) if kind == "resid" else None
+        return (lambda: ops.gemm(a, w, bias, act=ops.ACT_GEGLU if kind == "geglu" else ops.ACT_NONE, resid=resid)), 2.0 * M * N * K
+    B, H, W, C1, C2, Co = (int(v) for v in f[1:7])
+    st = int(f[7]) if len(f) > 7 else 1
+    ups = bool(int(f[8])) if len(f) > 8 else False
+    x = rnd(B, H, W, C1)
+    x2 = rnd(B, H, W, C2) if C2 else None
+    w = rnd(Co, 9 * (C1 + C2))
+    bias = torch.randn(Co, device=dev)
+    Ho = H * 2 if ups else (H // 2 if st == 2 else H)
+    return (lambda: ops.conv3x3(x, w, bias, x2=x2, stride=st, pad=1, upsample=ups)), 2.0 * B * Ho * Ho * Co * 9 * (C1 + C2)
+
+
+def main():
+    h = lib.load()
+    buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)          # room for 131072 workgroups
+    for spec in sys.argv[1:]:
+        call, fl = make(spec)
+        h.pbe_debug_set_stamps(None)
+        for _ in range(3):
+            call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(10):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / 10 * 1e3
+        buf.zero_()
+        ops._PLANS = []
+        h.pbe_debug_set_stamps(lib.c_vp(buf.data_ptr()))
+        call()
+        torch.cuda.synchronize()
+        h.pbe_debug_set_stamps(None)
+        plan, ops._PLANS = ops._PLANS[0], None
+        s = buf.cpu().numpy().reshape(-1, 8)
+        s = s[s[:, 0] != 0]
+        d = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5]], 1).astype(np.float64)
+        if plan[2] > 1:                                    # split-K workgroups end at the slab store: no stage / copy-out stamps
+            d[:, 4] = 0
+            d[:, 5] = s[:, 6] - s[:, 4]
+        tot = (s[:, 6] - s[:, 0]).astype(np.float64)
+        start = (s[:, 7] - s[:, 7].min()) / 100.0          # us after the first workgroup started (100 MHz wall clock)
+        span_us = start.max() + 0.0
+        print(f"== {spec}: {us:.1f} us ({fl / us / 1e6:.0f} TFLOP/s), tile {plan[3]}x{plan[4]} split {plan[2]}, {len(s)} workgroups; "
+              f"last workgroup starts {span_us:.1f} us after the first; median workgroup lifetime {np.median(tot):.0f} cycles")
+        for i, n in enumerate(NAMES):
+            print(f"   {n:9s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}  "
+                  f"({100 * np.median(d[:, i]) / np.median(tot):5.1f} % of a workgroup)")
+
+
+if __name__ == "__main__":
+    main()
