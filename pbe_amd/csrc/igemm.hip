@@ -41,7 +41,7 @@ struct IGemmP {
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
 #ifdef PBE_STAMPS
-    unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 8 s_memtime stamps per workgroup
+    unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 10 stamps per workgroup
 #endif
 };
 
@@ -52,7 +52,7 @@ struct IGemmP {
     do {                                                                                                               \
         if (p.stamps && threadIdx.x == 0) {                                                                            \
             const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                     \
-            p.stamps[wg_ * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();      \
+            p.stamps[wg_ * 10 + (i)] = (i) >= 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
         }                                                                                                              \
     } while (0)
 #else
@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             }
         }
         PBE_STAMP(6);
+        PBE_STAMP(8);
         return;
     }
 
@@ -468,6 +469,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         else copy_out(g, std::false_type{});
     }
     PBE_STAMP(6);                                    // stores issued
+    PBE_STAMP(8);                                    // wall clock (100 MHz) of the end
 }
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue: 4 columns per thread.

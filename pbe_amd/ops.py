@@ -130,9 +130,14 @@ class _timed:
         return False
 
 
+_FORCE_CFG = None         # set by tools/autotune_insitu.py: every GEMM / conv launch takes this tile_cfg (A/B inside the real sampler)
+
+
 def _tile_cfg(key: str) -> int:
     if _RECORD is not None:
         _RECORD[key] = _RECORD.get(key, 0) + 1
+    if _FORCE_CFG is not None:
+        return int(_FORCE_CFG)
     return int(_TUNED.get(key, -1))
 
 

@@ -52,9 +52,88 @@ def make(spec):
     return (lambda: ops.conv3x3(x, w, bias, x2=x2, stride=st, pad=1, upsample=ups)), 2.0 * B * Ho * Ho * Co * 9 * (C1 + C2)
 
 
-def main():
+def report(spec, s, plan, us, fl, out=sys.stdout):
+    s = s[s[:, 0] != 0]
+    d = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5]], 1).astype(np.float64)
+    if plan[2] > 1:                                    # split-K workgroups end at the slab store: no stage / copy-out stamps
+        d[:, 4] = 0
+        d[:, 5] = s[:, 6] - s[:, 4]
+    tot = (s[:, 6] - s[:, 0]).astype(np.float64)
+    wall = (s[:, 8] - s[:, 7]).astype(np.float64) / 100.0      # us per workgroup (100 MHz wall clock)
+    ghz = np.median(tot / np.maximum(wall, 1e-3)) / 1e3
+    start = (s[:, 7] - s[:, 7].min()) / 100.0
+    span = (s[:, 8].max() - s[:, 7].min()) / 100.0
+    print(f"== {spec}: {'%.1f us event-timed, ' % us if us else ''}{span:.1f} us first start -> last end ({fl / span / 1e6:.0f} TFLOP/s), tile {plan[3]}x{plan[4]} split {plan[2]}, "
+          f"{len(s)} workgroups; last start +{start.max():.1f} us; median lifetime {np.median(tot):.0f} cycles = {np.median(wall):.1f} us -> in-kernel clock {ghz:.2f} GHz", file=out)
+    for i, n in enumerate(NAMES):
+        print(f"   {n:9s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}  "
+              f"({100 * np.median(d[:, i]) / np.median(tot):5.1f} % of a workgroup)", file=out)
+
+
+def pipeline(keys):
+    """The same stamps taken INSIDE the real U-Net forward (batch 8): operands come from the producing kernels, weights from HBM."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import modelbuild
     h = lib.load()
-    buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)          # room for 131072 workgroups
+    buf = torch.zeros(10 << 17, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        model = modelbuild.full_model(dev)
+        unet = model.model.diffusion_model
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(8, 9, 64, 64, generator=g).to(dev)
+        ctx = torch.randn(8, 1, 768, generator=g).to(dev)
+        t = torch.full((8,), 621, dtype=torch.int64, device=dev)
+        x16 = ops.nchw_to_nhwc(x, unet.pk().cin_pad)
+        for _ in range(3):
+            unet.forward_nhwc(x16, t, ctx)
+        torch.cuda.synchronize()
+        got = {}
+        orig = {"gemm": ops.gemm, "conv3x3": ops.conv3x3}
+
+        def wrap(name):
+            fn = orig[name]
+
+            def w(*a, **k):
+                n0 = len(ops._PLANS)
+                # find the key this launch WILL have: run it stamped when it is a wanted, not yet captured key
+                buf.zero_()
+                h.pbe_debug_set_stamps(lib.c_vp(buf.data_ptr()))
+                out = fn(*a, **k)
+                h.pbe_debug_set_stamps(None)
+                plan = ops._PLANS[n0]
+                key = plan[0] + ("|r" if k.get("resid") is not None else "") + ("|geglu" if k.get("act") == ops.ACT_GEGLU else "")
+                if key in keys and key not in got:
+                    torch.cuda.synchronize()
+                    got[key] = (buf.cpu().numpy().reshape(-1, 10).copy(), plan)
+                return out
+            return w
+        ops._PLANS = []
+        ops.gemm, ops.conv3x3 = wrap("gemm"), wrap("conv3x3")
+        try:
+            unet.forward_nhwc(x16, t, ctx)
+        finally:
+            ops.gemm, ops.conv3x3 = orig["gemm"], orig["conv3x3"]
+            ops._PLANS = None
+    for key in keys:
+        if key not in got:
+            print(f"== {key}: not launched by the U-Net forward")
+            continue
+        s, plan = got[key]
+        f = key.split("|")[0].split(":")
+        if f[0] == "g":
+            fl = 2.0 * int(f[1]) * int(f[2]) * int(f[3])
+        else:
+            B, H, W, C1, C2, Co, st, pad, ups = (int(v) for v in f[1:10])
+            Ho, Wo = ops.conv_out_hw(H, W, st, pad, bool(ups))
+            fl = 2.0 * B * Ho * Wo * Co * 9 * (C1 + C2)
+        report("[in pipeline] " + key, s, plan, 0.0, fl)
+
+
+def main():
+    if sys.argv[1] == "--pipeline":
+        return pipeline(sys.argv[2:])
+    h = lib.load()
+    buf = torch.zeros(10 << 17, dtype=torch.int64, device=dev)          # room for 131072 workgroups
     for spec in sys.argv[1:]:
         call, fl = make(spec)
         h.pbe_debug_set_stamps(None)
@@ -75,20 +154,7 @@ def main():
         torch.cuda.synchronize()
         h.pbe_debug_set_stamps(None)
         plan, ops._PLANS = ops._PLANS[0], None
-        s = buf.cpu().numpy().reshape(-1, 8)
-        s = s[s[:, 0] != 0]
-        d = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5]], 1).astype(np.float64)
-        if plan[2] > 1:                                    # split-K workgroups end at the slab store: no stage / copy-out stamps
-            d[:, 4] = 0
-            d[:, 5] = s[:, 6] - s[:, 4]
-        tot = (s[:, 6] - s[:, 0]).astype(np.float64)
-        start = (s[:, 7] - s[:, 7].min()) / 100.0          # us after the first workgroup started (100 MHz wall clock)
-        span_us = start.max() + 0.0
-        print(f"== {spec}: {us:.1f} us ({fl / us / 1e6:.0f} TFLOP/s), tile {plan[3]}x{plan[4]} split {plan[2]}, {len(s)} workgroups; "
-              f"last workgroup starts {span_us:.1f} us after the first; median workgroup lifetime {np.median(tot):.0f} cycles")
-        for i, n in enumerate(NAMES):
-            print(f"   {n:9s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}  "
-                  f"({100 * np.median(d[:, i]) / np.median(tot):5.1f} % of a workgroup)")
+        report(spec, buf.cpu().numpy().reshape(-1, 10), plan, us, fl)
 
 
 if __name__ == "__main__":
