@@ -11,12 +11,13 @@ configs/v1.yaml architecture (no checkpoint exists offline).
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (driver, N > 1)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     dominant kernel class (3x3-conv implicit GEMM, MFMA-bound): algorithmic FLOP per
-               launch / average launch duration, measured with HIP events on the launch stream in a
-               separate profiled pass AFTER the timed region (pbe_prof_*), against 2.5 PFLOP/s dense fp16.
+  roofline     the kernel class with the most GPU time (3x3-conv implicit GEMM or the Linear GEMM, both MFMA): algorithmic
+               FLOP per launch / average launch duration, measured with HIP events on the launch stream in a separate
+               profiled pass AFTER the timed region (pbe_prof_*), against 2.5 PFLOP/s dense fp16; `classes` holds the same
+               for every kernel class plus `frac_of_binding_roofline` (per launch: max(FLOP / peak, bytes / 8 TB/s)).
   cpu_baseline the CPU oracle (a port: oracle/pbe_oracle.py, fp32 torch) timed on this box's host
-               cores on a bounded sample (1 CFG U-Net pair + VAE enc/dec + CLIP for one image),
-               extrapolated to images/sec.  Rank 0, N = 1 only.
+               cores on a bounded sample (warm-up + 3 CFG U-Net pairs, median; VAE enc/dec + CLIP for one image),
+               extrapolated to images/sec; CPU model and physical core count reported.  Rank 0, N = 1 only.
 """
 from __future__ import annotations
 
@@ -91,6 +92,7 @@ import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_IMAGE = 85.08e12          # 51*2*796.94 + 1116.7 + 2514.5 + 155.5 + 0.13 GFLOP
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_TBS = 8.0                 # HBM3E spec, same table (6.3 TB/s is what a streaming copy reaches)
 
 
 def log(msg):
@@ -129,8 +131,32 @@ def build_model(device, rank, world):
     return model, cpu_sd
 
 
-def cpu_baseline(cpu_sd, threads):
-    """Time the oracle (fp32 torch restatement of the reference) on the host: bounded sample."""
+def cpu_info():
+    """CPU model string and physical core count of the box (BASELINE.md section 3 asks for both beside the baseline)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return model, len(cores) or (os.cpu_count() or 1)
+
+
+def cpu_baseline(cpu_sd, threads, pairs=3):
+    """Time the oracle (fp32 torch restatement of the reference) on the host: bounded sample.  One untimed warm-up CFG pair, then
+    `pairs` timed pairs (median reported), VAE encode / decode and CLIP once each."""
+    import statistics
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pbe_oracle as O
     import cases
@@ -145,17 +171,39 @@ def cpu_baseline(cpu_sd, threads):
         t_enc = time.time() - t0
         x9 = torch.cat([inp["x_T"], z, O.resize_mask(inp["mask"], (64, 64))], 1)
         ctx = torch.cat([cpu_sd["learnable_vector"].float(), c])
-        t0 = time.time()
-        O.unet_forward(cpu_sd, torch.cat([x9] * 2), torch.full((2,), 981, dtype=torch.int64), ctx, prefix="model.diffusion_model.")
-        t_pair = time.time() - t0
+        t_pairs = []
+        for i in range(pairs + 1):                           # first one is the warm-up (allocator, thread pool, oneDNN primitives)
+            t0 = time.time()
+            O.unet_forward(cpu_sd, torch.cat([x9] * 2), torch.full((2,), 981 - 20 * i, dtype=torch.int64), ctx, prefix="model.diffusion_model.")
+            t_pairs.append(time.time() - t0)
+        t_pair = statistics.median(t_pairs[1:])
         t0 = time.time()
         O.first_stage_decode(cpu_sd, inp["x_T"] * 0.18215, prefix="first_stage_model.")
         t_dec = time.time() - t0
     per_image = 51 * t_pair + t_enc + t_dec + t_clip
+    model, phys = cpu_info()
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 CFG U-Net pair ({t_pair:.2f}s) + VAE encode ({t_enc:.2f}s) + decode ({t_dec:.2f}s) + CLIP+mapper ({t_clip:.2f}s) "
-                      f"for one 512x512 image, fp32 oracle; extrapolated x51 U-Net pairs",
-            "unet_s_per_step_per_image": t_pair}
+            "sample": f"warm-up + {pairs} timed CFG U-Net pairs (median {t_pair:.2f}s; all {', '.join('%.2f' % t for t in t_pairs[1:])}; warm-up {t_pairs[0]:.2f}s) "
+                      f"+ VAE encode ({t_enc:.2f}s) + decode ({t_dec:.2f}s) + CLIP+mapper ({t_clip:.2f}s) for one 512x512 image, fp32 oracle; "
+                      f"extrapolated x51 U-Net pairs",
+            "unet_s_per_step_per_image": t_pair, "cpu_model": model, "physical_cores": phys, "threads_used": threads}
+
+
+def measured_traffic():
+    """profiles/igemm_traffic.json (tools/pmc_bench_traffic.py over rocprofv3 --pmc passes of THIS command) - only when it was
+    taken with the library sources and tile table this run uses; otherwise (None, reason)."""
+    import hashlib
+    from pbe_amd import lib
+    path = os.path.join(ROOT, "profiles", "igemm_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/igemm_traffic.json"
+    with open(path) as f:
+        tj = json.load(f)
+    with open(os.path.join(ROOT, "pbe_amd", "tuned_mi355x.json"), "rb") as f:
+        table = hashlib.sha256(f.read()).hexdigest()[:16]
+    if tj.get("source_hash") != lib.source_hash() or tj.get("tuned_table_sha") != table:
+        return None, f"stale: taken with sources {tj.get('source_hash')} / table {tj.get('tuned_table_sha')}, this run uses {lib.source_hash()} / {table}"
+    return tj, "profiles/igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over this command)"
 
 
 def main():
@@ -230,25 +278,15 @@ def main():
         # ---- separate passes (outside the timed region): stage split and per-kernel-class events ----
         stage = {}
         one_step(timings=stage)
-        prof, conv_alg_bytes = None, None
+        prof = None
         if not a.no_profile:
             ops.prof_reset()
             ops.prof_enable(True)
-            ops._RECORD = {}                                   # shapes of this pass -> algorithmic bytes of the conv launches
             one_step()
             torch.cuda.synchronize()
             ops.prof_enable(False)
             prof = ops.prof_collect()
             ops.prof_reset()
-            shapes, ops._RECORD = ops._RECORD, None
-            nconv = alg = 0
-            for key, cnt in shapes.items():                    # c:B:H:W:C1:C2:Cout:stride:pad:ups — read x once, weights once, write y once (fp16)
-                if key.startswith("c:"):
-                    Bc, H, W, C1, C2, Co, st, pad, ups = (int(v) for v in key.split(":")[1:10])
-                    Ho, Wo = ops.conv_out_hw(H, W, st, pad, bool(ups))
-                    alg += cnt * 2 * (Bc * H * W * (C1 + C2) + Co * 9 * (C1 + C2) + Bc * Ho * Wo * Co)
-                    nconv += cnt
-            conv_alg_bytes = alg / nconv if nconv else None
 
     if rank != 0:
         if world > 1:
@@ -271,22 +309,35 @@ def main():
         "e2e_mfma_frac": value / world * FLOP_PER_IMAGE / (MFMA_PEAK_TFLOPS * 1e12),
     }
     if prof:
-        conv = prof["conv3x3_igemm"]
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")      # tools/pmc_bench_traffic.py (rocprofv3 --pmc passes over this command)
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            traffic, traffic_src = tj.get("traffic_B_per_launch"), "profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        tf = conv["work"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-        line["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel<*,*,1> (3x3 conv implicit GEMM)", "achieved": tf, "peak": MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "B per launch (L2-fabric side)",
-                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_alg_bytes, "launches": conv["launches"],
-                            "avg_launch_us": 1e3 * conv["ms"] / max(1, conv["launches"]),
-                            "avg_gflop_per_launch": conv["work"] / max(1, conv["launches"]) / 1e9}
-        line["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                      "rate": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
-                                      "rate_unit": "TFLOP/s" if k in ("conv3x3_igemm", "gemm", "attention") else "TB/s"} for k, v in prof.items()}
+        MFMA = ("conv3x3_igemm", "gemm", "attention")
+        tj, traffic_src = measured_traffic()
+        classes = {}
+        for k, v in prof.items():
+            if not v["launches"]:
+                continue
+            mf = k in MFMA
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0              # TFLOP/s (matrix-core classes) or TB/s
+            row = {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_launch_us": 1e3 * v["ms"] / v["launches"], "achieved": ach,
+                   "unit": "TFLOP/s" if mf else "TB/s", "peak": MFMA_PEAK_TFLOPS if mf else HBM_PEAK_TBS,
+                   "frac": ach / (MFMA_PEAK_TFLOPS if mf else HBM_PEAK_TBS),
+                   "algorithmic_bytes_per_launch": v["bytes"] / v["launches"],
+                   # per launch the roofline that binds THAT launch: max(FLOP / MFMA peak, algorithmic bytes / HBM peak), summed over the class
+                   "roofline_ms": round(v["roofline_ms"], 3), "frac_of_binding_roofline": v["roofline_ms"] / v["ms"] if v["ms"] > 0 else 0.0}
+            if mf:
+                row["gflop_per_launch"] = v["work"] / v["launches"] / 1e9
+            t = (tj or {}).get("classes", {}).get(k)
+            row["traffic"] = t["traffic_B_per_launch"] if t else None
+            classes[k] = row
+        dom = max((k for k in classes if k in MFMA), key=lambda k: classes[k]["ms"])           # the class with the most GPU time
+        d = classes[dom]
+        names = {"conv3x3_igemm": "igemm_kernel<*,*,*,*,1,*> (3x3 conv implicit GEMM)", "gemm": "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)",
+                 "attention": "attn_kernel<*,*,*> (fused self-attention)"}
+        line["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": d["frac"], "traffic": d["traffic"], "traffic_unit": "B per launch (L2-fabric side)", "traffic_source": traffic_src,
+                            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "launches": d["launches"],
+                            "avg_launch_us": d["avg_launch_us"], "avg_gflop_per_launch": d["gflop_per_launch"],
+                            "frac_of_binding_roofline": d["frac_of_binding_roofline"], "classes": classes}
+        line["kernel_classes"] = {k: {"launches": v["launches"], "ms": v["ms"], "rate": v["achieved"], "rate_unit": v["unit"]} for k, v in classes.items()}
     if world == 1 and not a.no_cpu_baseline and cpu_sd is not None:
         try:
             line["cpu_baseline"] = cpu_baseline(cpu_sd, max(1, min(16, os.cpu_count() or 1)))     # a 1-GPU box owns a 16-core share of the host

@@ -237,8 +237,9 @@ int pbe_tune(int32_t key, int32_t value);
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ---- */
 int pbe_prof_enable(int32_t on);
 int pbe_prof_reset(void);
-/* out[3*k + {0,1,2}] = {launches, total ms, total work (flop or bytes)} for class k; returns #classes.
- * Synchronises the recorded events (call outside any timed region). */
+/* out[5*k + {0..4}] = {launches, total ms, total work (FLOP for the matrix-core classes, bytes otherwise), total algorithmic bytes,
+ * roofline ms = sum over launches of max(FLOP / 2.5e15, bytes / 8e12) - the bound that binds each launch} for class k; returns
+ * #classes.  Synchronises the recorded events (call outside any timed region). */
 int pbe_prof_collect(double* out, int32_t max_classes);
 const char* pbe_prof_class_name(int32_t klass);
 

@@ -395,7 +395,8 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     else if (D <= 80) { if (two) launch_attn<80, 2>(p, s); else launch_attn<80, 1>(p, s); }
     else if (D <= 128) launch_attn<128, 1>(p, s);
     else launch_attn<160, 1>(p, s);
-    pbe_prof_end(PBE_K_ATTN, s, 4.0 * d->B * d->H * (double)d->Nq * d->Nk * d->D);
+    pbe_prof_end(PBE_K_ATTN, s, 4.0 * d->B * d->H * (double)d->Nq * d->Nk * d->D,
+                 2.0 * d->B * d->H * (double)d->D * (2.0 * d->Nq + 2.0 * d->Nk));                 // q, o, k, v^T once each
     PBE_LAUNCH_CHECK("pbe_attention_f16");
     return PBE_OK;
 }

@@ -35,7 +35,7 @@ int pbe_set_error(int code, const char* fmt, ...);
 
 // optional per-kernel-class event timing (pbe_prof_*), see profile.cpp
 void pbe_prof_begin(int klass, hipStream_t s);
-void pbe_prof_end(int klass, hipStream_t s, double work);
+void pbe_prof_end(int klass, hipStream_t s, double work, double bytes = 0.0);   // work = FLOP (MFMA classes) or bytes; bytes = algorithmic HBM bytes
 enum { PBE_K_CONV3 = 0, PBE_K_GEMM = 1, PBE_K_ATTN = 2, PBE_K_GNORM = 3, PBE_K_LNORM = 4, PBE_K_ELEM = 5, PBE_K_SOFTMAX = 6, PBE_K_SPLITK = 7, PBE_K_COUNT = 8 };
 
 // ---- device helpers -------------------------------------------------------------------------

@@ -617,7 +617,13 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     pbe_prof_begin(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
-    pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch);
+    {   // algorithmic bytes: every operand once (fp16): activations, weights, output, fused residual
+        const double nout = p.act == PBE_ACT_GEGLU ? p.N * 0.5 : (double)p.N;
+        const double a_el = MODE == 1 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
+        const double w_el = (double)p.N * p.K * ((MODE == 0 && p.sW) ? batch : 1);
+        const double c_el = (double)p.M * nout * batch * (p.resid ? 2.0 : 1.0);
+        pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch, 2.0 * (a_el + w_el + c_el));
+    }
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
         pbe_prof_begin(PBE_K_SPLITK, s);

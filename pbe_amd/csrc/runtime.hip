@@ -27,7 +27,7 @@ extern "C" const char* pbe_source_hash(void) { return PBE_SRC_HASH; }
 // Off by default (zero overhead: one relaxed load).  bench.py turns it on for ONE profiled pass
 // outside the timed region, so the events never perturb the reported throughput.
 namespace {
-struct Rec { int klass; hipEvent_t a, b; double work; };
+struct Rec { int klass; hipEvent_t a, b; double work, bytes; };
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -51,13 +51,13 @@ void pbe_prof_begin(int klass, hipStream_t s) {
     if (t_open) (void)hipEventRecord(t_open, s);
 }
 
-void pbe_prof_end(int klass, hipStream_t s, double work) {
+void pbe_prof_end(int klass, hipStream_t s, double work, double bytes) {
     if (!g_on || !t_open) return;
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t b = get_event();
     if (b) {
         (void)hipEventRecord(b, s);
-        g_recs.push_back(Rec{klass, t_open, b, work});
+        g_recs.push_back(Rec{klass, t_open, b, work, bytes});
     }
     t_open = nullptr;
 }
@@ -71,17 +71,25 @@ extern "C" int pbe_prof_reset(void) {
     return PBE_OK;
 }
 
+// out[5 k + {0..4}] = {launches, total ms, total work, total algorithmic bytes, roofline ms} of class k.  "roofline ms" sums, per
+// launch, the time the launch would take at the roofline that binds IT: max(FLOP / 2.5 PFLOP/s dense fp16 MFMA, bytes / 8 TB/s
+// HBM3E) for the matrix-core classes (a K = 320 GEMM is HBM-bound, a 3x3 conv MFMA-bound), bytes / 8 TB/s for the others.
 extern "C" int pbe_prof_collect(double* out, int32_t max_classes) {
     if (!out || max_classes < PBE_K_COUNT) return pbe_set_error(PBE_EINVAL, "pbe_prof_collect: need room for %d classes", PBE_K_COUNT);
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int i = 0; i < 3 * PBE_K_COUNT; ++i) out[i] = 0.0;
+    for (int i = 0; i < 5 * PBE_K_COUNT; ++i) out[i] = 0.0;
     for (auto& r : g_recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-        out[3 * r.klass + 0] += 1.0;
-        out[3 * r.klass + 1] += (double)ms;
-        out[3 * r.klass + 2] += r.work;
+        const bool mfma = r.klass == PBE_K_CONV3 || r.klass == PBE_K_GEMM || r.klass == PBE_K_ATTN;
+        const double bytes = mfma ? r.bytes : r.work;
+        const double t_mfma = mfma ? r.work / 2.5e15 : 0.0, t_hbm = bytes / 8.0e12;
+        out[5 * r.klass + 0] += 1.0;
+        out[5 * r.klass + 1] += (double)ms;
+        out[5 * r.klass + 2] += r.work;
+        out[5 * r.klass + 3] += bytes;
+        out[5 * r.klass + 4] += 1e3 * (t_mfma > t_hbm ? t_mfma : t_hbm);
     }
     return PBE_K_COUNT;
 }

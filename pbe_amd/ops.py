@@ -527,9 +527,10 @@ def prof_reset() -> None:
 
 def prof_collect():
     lib = _l.load()
-    buf = (C.c_double * (3 * 16))()
+    buf = (C.c_double * (5 * 16))()
     n = lib.pbe_prof_collect(buf, 16)
     out = {}
     for k in range(n):
-        out[lib.pbe_prof_class_name(k).decode()] = {"launches": int(buf[3 * k]), "ms": buf[3 * k + 1], "work": buf[3 * k + 2]}
+        out[lib.pbe_prof_class_name(k).decode()] = {"launches": int(buf[5 * k]), "ms": buf[5 * k + 1], "work": buf[5 * k + 2],
+                                                    "bytes": buf[5 * k + 3], "roofline_ms": buf[5 * k + 4]}
     return out

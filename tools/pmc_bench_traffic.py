@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 PMC passes over the SAME `bench.py` command to the HBM-side traffic per launch of
-the dominant kernel (the 3x3-conv implicit GEMM, igemm_kernel<..., MODE = 1>), as bench.py's
-`roofline.traffic` wants it.  Counters collected exactly as MI355X_MICROARCH.md §HBM prescribes:
+the two implicit-GEMM kernel classes (3x3 conv: igemm_kernel<..., MODE = 1, S>; Linear / 1x1 GEMM: MODE = 0), as bench.py's
+`roofline.traffic` / `roofline.classes.*.traffic` want it, stamped with the library source hash and the tile-table hash.  Counters collected exactly as MI355X_MICROARCH.md §HBM prescribes:
 
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_bench/f -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_bench/w -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
-    python tools/pmc_bench_traffic.py gpurun_out/pmc_bench/f gpurun_out/pmc_bench/w profiles/conv_traffic.json
+    python tools/pmc_bench_traffic.py gpurun_out/pmc_bench/f gpurun_out/pmc_bench/w profiles/igemm_traffic.json
 
 (separate passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  Units and gfx950 corrections:
 both counters are KiB; FETCH_SIZE tallies 64 B per 128-B request for wide (16 B / lane) coalesced reads —
@@ -37,25 +37,37 @@ def per_kernel(d, counter):
 
 
 def main(fdir, wdir, outp):
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from pbe_amd import lib
     ft, fn = per_kernel(fdir, "FETCH_SIZE")
     wt, wn = per_kernel(wdir, "WRITE_SIZE")
-    def is_conv(k):                                   # igemm_kernel<BM, BN, NWM, NWN, MODE, S>: MODE 1 = 3x3 conv
+
+    def mode_of(k):                                   # igemm_kernel<BM, BN, NWM, NWN, MODE, S>: MODE 1 = 3x3 conv, 0 = dense GEMM
         if not k.startswith("igemm_kernel<"):
-            return False
+            return None
         args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-        return len(args) >= 5 and args[4] == "1"
-    conv = [k for k in ft if is_conv(k)]
-    launches = sum(fn[k] for k in conv)
-    assert launches and launches == sum(wn[k] for k in conv), (launches, sum(wn[k] for k in conv))
-    rd = sum(ft[k] for k in conv) * 1024 * 2
-    wr = sum(wt[k] for k in conv) * 1024
-    rows = {k: {"launches": fn[k], "read_B_per_launch": ft[k] * 2048 / fn[k], "write_B_per_launch": wt[k] * 1024 / max(1, wn[k])} for k in sorted(conv)}
-    out = {"kernel": "igemm_kernel<*,*,*,*,1> (3x3 conv implicit GEMM)", "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile (2 passes of the hot path)",
-           "launches": launches, "read_B_per_launch": rd / launches, "write_B_per_launch": wr / launches, "traffic_B_per_launch": (rd + wr) / launches,
-           "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950: 64 B tallied per 128-B request); WRITE_SIZE KiB x 1024", "per_tile_config": rows}
+        return args[4] if len(args) >= 5 else None
+    classes = {}
+    for cname, mode, label in (("conv3x3_igemm", "1", "igemm_kernel<*,*,*,*,1,*> (3x3 conv implicit GEMM)"), ("gemm", "0", "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)")):
+        ks = [k for k in ft if mode_of(k) == mode]
+        launches = sum(fn[k] for k in ks)
+        assert launches and launches == sum(wn[k] for k in ks), (cname, launches, sum(wn[k] for k in ks))
+        rd = sum(ft[k] for k in ks) * 1024 * 2
+        wr = sum(wt[k] for k in ks) * 1024
+        classes[cname] = {"kernel": label, "launches": launches, "read_B_per_launch": rd / launches, "write_B_per_launch": wr / launches,
+                          "traffic_B_per_launch": (rd + wr) / launches,
+                          "per_tile_config": {k: {"launches": fn[k], "read_B_per_launch": ft[k] * 2048 / fn[k], "write_B_per_launch": wt[k] * 1024 / max(1, wn[k])}
+                                              for k in sorted(ks)}}
+    with open(os.path.join(root, "pbe_amd", "tuned_mi355x.json"), "rb") as f:
+        table = hashlib.sha256(f.read()).hexdigest()[:16]
+    out = {"command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile (2 passes of the hot path)", "source_hash": lib.source_hash(), "tuned_table_sha": table,
+           "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950: 64 B tallied per 128-B request); WRITE_SIZE KiB x 1024", "classes": classes}
     with open(outp, "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps({k: v for k, v in out.items() if k != "per_tile_config"}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_tile_config"} for k, v in classes.items()}, indent=1))
 
 
 if __name__ == "__main__":
