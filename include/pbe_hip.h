@@ -79,7 +79,7 @@ typedef struct pbe_gemm_desc {
     int32_t bias_per_row;
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
-    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..9) | (split-K factor << 8), factor 0 = library's choice */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..14; 10..14 are the halo-resident conv tiles and apply to stride-1 3x3 convs only) | (split-K factor << 8), factor 0 = library's choice */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 /* Plan / workspace query for the SAME descriptor (nothing is launched): out6 = {tile config index, split-K factor,

@@ -37,6 +37,7 @@ struct IGemmP {
     float alpha; int act; int bias_row; int vec;
     // conv gather
     int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 64)
+    int th;                                              // MODE 2: image rows per tile (tile = th full rows, or whole images)
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
@@ -68,8 +69,14 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    // MODE 2 = 3x3 conv (stride 1, pad 1) with the activation HALO resident in LDS: a tile is BM pixels = whole image rows (or whole
+    // images); for every 64-channel block its (rows + 2) x (width + 2) halo (HPA rows of 128 B, zero outside the image) is staged
+    // ONCE and all 9 taps read their shifted windows from it, so only the weight tile streams per k-tile.  MODE 1 re-stages the
+    // activation tile for every tap: with two 128x160 workgroups per CU that is 74 KB of LDS-DMA per 1 280 MFMA pipe cycles -
+    // more than a CU's fill path delivers (phase stamps: 3 190 cycles per k-tile inside the sampler).  Here a 256x160 tile moves
+    // 20.5 KB + 5.7 KB for the same MFMA work.  S = weight ring depth.
     // S = LDS ring depth (S - 1 k-tiles of 64 in flight).  Sized per tile so the ring fills the LDS one workgroup (8-wave tiles)
     // or two to three workgroups (4-wave tiles) can own on a CU.
     // (A "ping-pong" form of the main loop for the 8-wave tiles - wave groups 0-3 / 4-7 offset by one barrier, [fragment reads +
@@ -80,9 +87,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     constexpr int PA = BM / 8, PW = BN / 8;           // 8-row x 128-byte DMA pieces (1 KiB = one wave instruction)
-    constexpr int LA = PA / NW, LW = PW / NW, LPT = LA + LW;
+    constexpr int LA = PA / NW, LW = (PW + NW - 1) / NW, LPT = LA + LW;
     constexpr int CLD = BN + 8;
-    static_assert(S >= 2 && S <= 4 && PA % NW == 0 && PW % NW == 0 && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
+    // MODE 2 LDS: [halo image 0][halo image 1][weight ring S x BN rows][1 KiB dump for the padding DMAs]
+    constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES + 1024 : S * STAGE;
+    static_assert(S >= 2 && S <= 4 && PA % NW == 0 && (PW % NW == 0 || MODE == 2) && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
+    static_assert(MODE != 2 || (HPA % 8 == 0 && HPA >= BM), "halo image must hold the tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,10 +133,10 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     // the shifted re-reads hit L2 instead of going back to the Infinity Cache / HBM (measured: tap-major order re-fetched the
     // input 9x beyond L2).  The tap -> input-pixel map of this tile's BM rows is built once into LDS:
     // tab[tap][row] = pixel index, or -1 outside the (virtual) image.
-    int* tab = reinterpret_cast<int*>(smem + S * STAGE);
+    int* tab = reinterpret_cast<int*>(smem + RING);
     // Epilogue vectors of this tile, staged ONCE (their global latency hides under the first DMA tile):
     // svec[s][c] = bias[n0 + c] + rowvec[first sample of the tile + s][n0 + c], up to 4 samples per tile.
-    float* svec = reinterpret_cast<float*>(smem + (S * STAGE > WM * CLD * 2 ? S * STAGE : WM * CLD * 2) + (MODE == 1 ? 9 * BM * 4 : 0));
+    float* svec = reinterpret_cast<float*>(smem + (RING > WM * CLD * 2 ? RING : WM * CLD * 2) + (MODE == 1 ? 9 * BM * 4 : 0));
     const int sv_ns = (p.rowvec && p.group_rows < BM) ? BM / p.group_rows : 1;       // samples per tile (tile is sample-aligned when sv_ok)
     if (MODE == 1) {
         const int hw = p.Ho * p.Wo, Hv = p.H << p.ups, Wv = p.Wd << p.ups;
@@ -150,7 +160,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
         const int n = n0 + (wave + NW * i) * 8 + lrow;
-        w_ok[i] = n < p.N;
+        w_ok[i] = n < p.N && wave + NW * i < PW;
         w_row[i] = p.W + bz * p.sW + (long)(w_ok[i] ? n : 0) * p.ldw;
     }
     const int nk_all = (p.K + 63) >> 6;
@@ -224,27 +234,162 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const int rsw = (fq ^ (fr & 7)) << 4;             // byte offset of k-step 0's chunk; k-step 1 is rsw ^ 64
     const int a_rd = (wm * WM + fr) * 128, w_rd = (wn * WN + fr) * 128;
 
+    auto stage_svec = [&]() {
+        if (p.sv_ok && p.splits <= 1) {                  // staged AFTER the first DMAs are in flight: both latencies overlap
+            const int s0 = p.rowvec ? m0 / p.group_rows : 0;
+            for (int idx = tid; idx < sv_ns * BN; idx += NT) {
+                const int si = idx / BN, c = idx - si * BN, n = n0 + c;
+                float v = 0.f;
+                if (n < p.N) {
+                    if (p.bias && !p.bias_row) v = p.bias[n];
+                    if (p.rowvec && (long)(s0 + si) * p.group_rows < p.M) v += (float)p.rowvec[(long)(s0 + si) * p.ldv + n];
+                }
+                svec[si * BN + c] = v;
+            }
+        }
+    };
+    // Tiles with few accumulators fetch BOTH k-steps' fragments before the first MFMA (the second set's LDS latency hides
+    // under the first set's MFMAs); the 256-row tiles have no registers for that and read k-step 1 after issuing k-step 0.
+    constexpr bool BOTH = TM * TN * 4 + 2 * (TM + TN) * 4 <= 176;
+
+    if constexpr (MODE == 2) {
+        constexpr int PAH = HPA / 8, LAH = (PAH + NW - 1) / NW;
+        unsigned char* abuf = smem;
+        unsigned char* wring = smem + 2 * HPA * 128;
+        unsigned char* dump = wring + S * W_BYTES;
+        const int TW = p.Wd, TH = p.th, HW2 = TW + 2, HPS = (TH + 2) * HW2;      // halo rows of one image of the tile
+        const int img_px = TH * TW, nsub = BM / img_px;                             // nsub > 1: the tile holds nsub whole images
+        const int tiles_per_img = p.H / TH;
+        const int b0 = nsub > 1 ? tm_i * nsub : tm_i / tiles_per_img;
+        const int y0 = nsub > 1 ? 0 : (tm_i - b0 * tiles_per_img) * TH;
+        int hpix[LAH];                                // source pixel of this lane's row in each of its halo pieces (-1: zero)
+#pragma unroll
+        for (int i = 0; i < LAH; ++i) {
+            const int piece = wave + NW * i, hp = piece * 8 + lrow;
+            int pix = -1;
+            if (piece < PAH && hp < nsub * HPS) {
+                const int sub = hp / HPS, r = hp - sub * HPS, hy = r / HW2, hx = r - hy * HW2;
+                const int y = y0 + hy - 1, x = hx - 1;
+                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)TW) pix = ((b0 + sub) * p.H + y) * TW + x;
+            }
+            hpix[i] = pix;
+        }
+        int hc[TM];                                   // halo row of this lane's pixel in each of its 16-pixel groups (tap (1,1))
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int ml = wm * WM + j * 16 + fr, sub = ml / img_px, rr = ml - sub * img_px, ty = rr / TW, tx = rr - ty * TW;
+            hc[j] = sub * HPS + (ty + 1) * HW2 + tx + 1;
+        }
+        auto issue_a = [&](int blk, int buf) {
+            const int c0b = blk * 64;
+            const bool first = c0b < p.C1;
+            const h16* base = (first ? p.A + c0b : p.A2 + (c0b - p.C1)) + gch * 8;
+            const long cs = first ? p.C1 : p.C2;
+#pragma unroll
+            for (int i = 0; i < LAH; ++i) {
+                const int piece = wave + NW * i;
+                PBE_GLDS16(hpix[i] >= 0 ? base + (long)hpix[i] * cs : zsrc, piece < PAH ? abuf + buf * (HPA * 128) + piece * 1024 : dump);
+            }
+        };
+        auto issue_w = [&](int kt, int slot) {
+            const int k = kt * 64 + gch * 8;
+#pragma unroll
+            for (int i = 0; i < LW; ++i) {
+                const int piece = wave + NW * i;
+                PBE_GLDS16(w_ok[i] ? w_row[i] + k : zsrc, (PW % NW == 0 || piece < PW) ? wring + slot * W_BYTES + piece * 1024 : dump);
+            }
+        };
+        const int nblk_all = (p.C1 + p.C2) >> 6;
+        int blk0 = 0, blk1 = nblk_all;                // this workgroup's channel blocks (split-K at block granularity)
+        if (p.splits > 1) {
+            const int per = (nblk_all + p.splits - 1) / p.splits;
+            blk0 = blockIdx.z * per;
+            blk1 = min(nblk_all, blk0 + per);
+        }
+        const int nk2 = blk1 * 9;
+        PBE_STAMP(1);
+        if (blk0 < blk1) {
+            issue_a(blk0, 0);
+#pragma unroll
+            for (int t = 0; t < D; ++t) issue_w(blk0 * 9 + t, t);
+        }
+        PBE_STAMP(2);
+        stage_svec();
+        int slot_rd = 0, slot_wr = D % S;
+        for (int blk = blk0; blk < blk1; ++blk) {
+            const unsigned char* ab = abuf + ((blk - blk0) & 1) * (HPA * 128);
+            const bool next_a = blk + 1 < blk1;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {          // (not unrolled: 9 copies of the body cost registers and 30 000 lines of ISA)
+                const int kt = blk * 9 + tap;
+#ifdef PBE_STAMPS
+                if (kt == blk0 * 9 + 1) PBE_STAMP(3);
+#endif
+                // W(kt) must have landed.  Younger DMAs that may stay in flight: the later W tiles (D - 1, fewer at the end) and,
+                // at taps 1 .. D, the halo pieces of block blk + 1 (issued at tap 0 right after W(kt0 + D)).  The halo of THIS
+                // block is older than W(kt) (in-order vmcnt), so it has landed too.
+                const int wleft = min(nk2 - 1 - kt, D - 1);
+                const bool a_young = next_a && tap >= 1 && tap <= D;
+                if (a_young) {
+                    if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
+                    else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
+                    else wait_vmcnt<LAH>();
+                } else {
+                    if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW>();
+                    else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
+                    else wait_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const unsigned char* sw = wring + slot_rd * W_BYTES;
+                const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+                const int shift = (trow - 1) * HW2 + (tap - 3 * trow - 1);
+                h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
+                int arow[TM];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) arow[j] = hc[j] + shift;
+#pragma unroll
+                for (int ks = 0; ks < (BOTH ? 2 : 1); ++ks) {
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((ks * 4 + fq) ^ (arow[j] & 7)) << 4));
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + D < nk2) issue_w(kt + D, slot_wr);
+                if (tap == 0 && next_a) issue_a(blk + 1, (blk + 1 - blk0) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+                if constexpr (!BOTH) {
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        fa[0][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((4 + fq) ^ (arow[j] & 7)) << 4));
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ 64) + i * 16 * 128);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+                slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+            }
+        }
+    } else {
     PBE_STAMP(1);                                    // loader state (+ tap table) ready
 #pragma unroll
     for (int t = 0; t < D; ++t)
         if (kt0 + t < nk) issue(kt0 + t, t);
     PBE_STAMP(2);                                    // ring primed (issue only)
-    if (p.sv_ok && p.splits <= 1) {                  // staged AFTER the first DMAs are in flight: both latencies overlap
-        const int s0 = p.rowvec ? m0 / p.group_rows : 0;
-        for (int idx = tid; idx < sv_ns * BN; idx += NT) {
-            const int si = idx / BN, c = idx - si * BN, n = n0 + c;
-            float v = 0.f;
-            if (n < p.N) {
-                if (p.bias && !p.bias_row) v = p.bias[n];
-                if (p.rowvec && (long)(s0 + si) * p.group_rows < p.M) v += (float)p.rowvec[(long)(s0 + si) * p.ldv + n];
-            }
-            svec[si * BN + c] = v;
-        }
-    }
-
-    // Tiles with few accumulators fetch BOTH k-steps' fragments before the first MFMA (the second set's LDS latency hides
-    // under the first set's MFMAs); the 256-row tiles have no registers for that and read k-step 1 after issuing k-step 0.
-    constexpr bool BOTH = TM * TN * 4 + 2 * (TM + TN) * 4 <= 176;
+    stage_svec();
     int slot_rd = 0, slot_wr = D % S;
     for (int kt = kt0; kt < nk; ++kt) {
 #ifdef PBE_STAMPS
@@ -289,6 +434,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         __builtin_amdgcn_s_setprio(0);
         slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
         slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PBE_STAMP(4);                                    // main loop issued
@@ -524,7 +670,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IGemmP p) {
 // ---- host side --------------------------------------------------------------------------------
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 struct Plan { int cfg; int splits; };
-struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; };
+struct TileCfg { int bm, bn, nwm, nwn, slots_per_cu; double eff; int hpa; };      // hpa > 0: halo-resident conv tile (MODE 2), rows of its halo image
 // eff = relative per-FLOP efficiency of the tile when the chip is full (ordered by staged bytes per FLOP).
 // Ring depth per tile (k-tiles of 64): the deepest that fits the LDS share of the tile's workgroups per CU.
 static const TileCfg kCfg[] = {
@@ -537,7 +683,13 @@ static const TileCfg kCfg[] = {
     {64, 64, 2, 2, 4, 0.60},             // 6: S = 2,  32 KiB
     {256, 320, 2, 4, 1, 1.05},           // 7: S = 2, 144 KiB: N = 320 / 640 / 960 / 1280 without column padding (142 FLOP per staged byte)
     {128, 320, 2, 4, 1, 0.96},           // 8: S = 2, 112 KiB: same, half the rows: fills the chip when M / 256 < 256 tiles
-    {128, 160, 2, 2, 2, 0.90}};          // 9: S = 2,  72 KiB, 4 waves: two workgroups per CU overlap each other's prologue / epilogue
+    {128, 160, 2, 2, 2, 0.90},           // 9: S = 2,  72 KiB, 4 waves: two workgroups per CU overlap each other's prologue / epilogue
+    // halo-resident 3x3 conv tiles (stride 1, pad 1, image width 8 .. 128 = tile width): only the weights stream per k-tile
+    {256, 160, 4, 2, 1, 1.40, 400},      // 10: weight ring 2, 143 KiB: 256 pixels (4 rows at 64x64) x 160 channels, 8 waves
+    {128, 160, 4, 2, 1, 1.20, 264},      // 11: weight ring 3, 129 KiB: 128 pixels x 160 channels
+    {128, 320, 2, 4, 1, 1.25, 264},      // 12: weight ring 2, 150 KiB: 128 pixels x 320 channels
+    {256, 128, 4, 2, 1, 1.30, 400},      // 13: weight ring 3, 152 KiB: channel counts that are multiples of 128 only
+    {128, 128, 4, 2, 1, 1.10, 400}};     // 14: weight ring 3, 152 KiB: one 128-pixel row of a 128-wide image (VAE)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 #ifdef PBE_STAMPS
@@ -546,6 +698,15 @@ extern "C" int pbe_debug_set_stamps(void* buf) { g_pbe_stamps = (unsigned long l
 #endif
 int g_pbe_force_cfg = -1;        // pbe_tune(1, cfg index [| splits << 8]) forces a tile config (and split-K factor); -1 = heuristic
 int g_pbe_allow_splitk = 1;      // pbe_tune(2, 0/1)
+
+// k-tiles of 64 per split-K granule: a halo tile splits at channel-block boundaries (9 taps)
+static inline int no_empty_slices(int nk, int granule, int s) {
+    const int units = (nk + granule - 1) / granule;
+    if (s > units) s = units;
+    if (s < 2) return 1;
+    const int per = (units + s - 1) / s;
+    return (units + per - 1) / per;
+}
 
 static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_bytes, long tiles) {
     if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) return 1;
@@ -556,20 +717,31 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
     if (s > nk / 4) s = nk / 4;
     if (s > 32) s = 32;
     while (s > 1 && (size_t)s * p.M * p.N * sizeof(float) > ws_bytes) --s;
-    if (s < 2) return 1;
-    const int per = (nk + s - 1) / s;
-    return (nk + per - 1) / per;                      // no empty slice
+    return no_empty_slices(nk, c.hpa ? 9 : 1, s);
 }
 
 // Shallow-K problems (< 20 k-tiles) are dominated by the prologue / epilogue, deep-K problems by staged bytes per
 // FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
-static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97};
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1};
+
+// Can this conv run as a halo-resident tile of bm pixels with a halo image of hpa rows?  Returns the image rows per tile (0: no).
+static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
+    if (mode != 1 || p.cstride != 1 || p.pad != 1 || p.ups || p.cb != 64) return 0;
+    const int W = p.Wd, H = p.H;
+    if (W < 8 || W > 128 || (W & (W - 1)) || bm % W || (p.M % bm)) return 0;
+    const int th = bm / W < H ? bm / W : H;
+    if (H % th) return 0;
+    const int nsub = bm / (th * W);                               // whole images per tile when the image is smaller than the tile
+    if (nsub > 1 && th != H) return 0;
+    if (nsub * (th + 2) * (W + 2) > hpa) return 0;
+    return th;
+}
 
 // want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
 // A requested factor is clamped to what the problem allows (batch 1, >= 4 k-tiles of 64 per slice, slabs fit the workspace).
-static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg) {
+static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int mode) {
     Plan best{3, 1};
     double best_score = -1.0;
     const int want = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : want_cfg;
@@ -579,6 +751,8 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];
+        if (t.hpa && !halo_rows(p, mode, t.bm, t.hpa)) continue;              // a forced halo tile that does not apply falls back below
+        if (t.hpa && p.N % 8) continue;
         if (shallow) t.eff = kEffShallow[c];
         const long tm = (p.M + t.bm - 1) / t.bm, tn = (p.N + t.bn - 1) / t.bn;
         const long tiles = tm * tn * batch;
@@ -589,8 +763,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
             if (!g_pbe_allow_splitk || batch != 1 || !p.ws || (p.N & 3) || (p.ldc & 3) || (p.resid && (p.ldr & 3))) sp = 1;
             if (sp > nk / 4) sp = nk / 4;
             while (sp > 1 && (size_t)sp * p.M * p.N * sizeof(float) > ws_bytes) --sp;
-            if (sp < 2) sp = 1;
-            else { const int per = (nk + sp - 1) / sp; sp = (nk + per - 1) / per; }
+            sp = no_empty_slices(nk, t.hpa ? 9 : 1, sp);
         }
         const double useful = (double)p.M * p.N * batch / ((double)tiles * t.bm * t.bn);
         const double blocks = (double)tiles * sp, slots = 256.0 * t.slots_per_cu;
@@ -600,29 +773,37 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
         const double score = t.eff * useful * (0.30 + 0.70 * quant) * split_cost;
         if (score > best_score) { best_score = score; best = Plan{c, sp}; }
     }
+    if (best_score < 0.0 && forced >= 0) {            // the requested tile cannot run this problem: let the heuristic choose
+        IGemmP q = p;
+        const int keep = g_pbe_force_cfg;
+        g_pbe_force_cfg = -1;
+        best = plan_igemm(q, batch, ws_bytes, -1, mode);
+        g_pbe_force_cfg = keep;
+    }
     return best;
 }
 
-template <int BM, int BN, int NWM, int NWN, int S, int MODE>
+template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
-    constexpr size_t ring = (size_t)S * (BM + BN) * 128;
+    constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 + 1024 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float);   // + svec[4][BN]
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
-    pbe_prof_begin(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;
+    pbe_prof_begin(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     {   // algorithmic bytes: every operand once (fp16): activations, weights, output, fused residual
         const double nout = p.act == PBE_ACT_GEGLU ? p.N * 0.5 : (double)p.N;
-        const double a_el = MODE == 1 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
+        const double a_el = MODE != 0 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
         const double w_el = (double)p.N * p.K * ((MODE == 0 && p.sW) ? batch : 1);
         const double c_el = (double)p.M * nout * batch * (p.resid ? 2.0 : 1.0);
-        pbe_prof_end(MODE == 1 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch, 2.0 * (a_el + w_el + c_el));
+        pbe_prof_end(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch, 2.0 * (a_el + w_el + c_el));
     }
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
@@ -634,7 +815,7 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
 
 template <int MODE>
 static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int want_cfg) {
-    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg);
+    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg, MODE);
     p.splits = pl.splits;
 #ifdef PBE_STAMPS
     p.stamps = g_pbe_stamps;
@@ -649,6 +830,11 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
         case 7: launch_cfg<256, 320, 2, 4, 2, MODE>(p, batch, s); break;
         case 8: launch_cfg<128, 320, 2, 4, 2, MODE>(p, batch, s); break;
         case 9: launch_cfg<128, 160, 2, 2, 2, MODE>(p, batch, s); break;
+        case 10: if constexpr (MODE == 1) launch_cfg<256, 160, 4, 2, 2, 2, 400>(p, batch, s); break;
+        case 11: if constexpr (MODE == 1) launch_cfg<128, 160, 4, 2, 3, 2, 264>(p, batch, s); break;
+        case 12: if constexpr (MODE == 1) launch_cfg<128, 320, 2, 4, 2, 2, 264>(p, batch, s); break;
+        case 13: if constexpr (MODE == 1) launch_cfg<256, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
+        case 14: if constexpr (MODE == 1) launch_cfg<128, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
         default: launch_cfg<64, 64, 2, 2, 2, MODE>(p, batch, s); break;
     }
 }
@@ -701,8 +887,8 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     return PBE_OK;
 }
 
-static void report_plan(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int32_t* out) {
-    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg);
+static void report_plan(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int32_t* out, int mode) {
+    const Plan pl = plan_igemm(p, batch, ws_bytes, want_cfg, mode);
     const TileCfg& t = kCfg[pl.cfg];
     out[0] = pl.cfg; out[1] = pl.splits; out[2] = t.bm; out[3] = t.bn;
     out[4] = cdiv(p.M, t.bm) * cdiv(p.N, t.bn) * batch * pl.splits;                       // workgroups launched
@@ -714,7 +900,7 @@ extern "C" int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* work
     IGemmP p;
     const int rc = fill_gemm(d, p, "pbe_gemm_plan");
     if (rc != PBE_OK) return rc;
-    report_plan(p, d->batch, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6);
+    report_plan(p, d->batch, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 0);
     *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
     return PBE_OK;
 }
@@ -767,7 +953,7 @@ extern "C" int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t
     IGemmP p;
     const int rc = fill_conv(d, p, "pbe_conv3x3_plan");
     if (rc != PBE_OK) return rc;
-    report_plan(p, 1, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6);
+    report_plan(p, 1, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 1);
     *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
     return PBE_OK;
 }

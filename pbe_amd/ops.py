@@ -490,13 +490,12 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional
 
 
 def conv_kblock(c1: int, c2: int = 0) -> int:
-    """Channel block of the conv K order for a layer whose input is c1 (+ c2 concatenated) channels
-    (deterministic, shared by pack_conv3x3 and conv3x3): the largest of 320 / 256 / 128 / 64 dividing both (the kernel walks K in
-    tiles of 64 channels; a block's 9 taps are 9 * cb / 64 consecutive k-tiles, so a pixel's shifted re-reads stay L2 hits)."""
-    for cb in (320, 256, 128, 64):
-        if c1 % cb == 0 and (c2 == 0 or c2 % cb == 0):
-            return cb
-    raise _l.PbeError(f"conv: C1={c1} / C2={c2} are not multiples of 64")
+    """Channel block of the conv K order (deterministic, shared by pack_conv3x3 and conv3x3): 64, the kernels' k-tile.  k = ((ci // 64)
+    * 9 + tap) * 64 + ci % 64: the 9 taps of a 64-channel block are consecutive k-tiles, which is what the halo-resident tiles need
+    (one halo image per block serves its 9 taps) and keeps the gather kernel's shifted re-reads within 9 k-tiles (L2 hits)."""
+    if c1 % 64 or c2 % 64:
+        raise _l.PbeError(f"conv: C1={c1} / C2={c2} are not multiples of 64")
+    return 64
 
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:

@@ -134,6 +134,8 @@ def main():
         return pipeline(sys.argv[2:])
     h = lib.load()
     buf = torch.zeros(10 << 17, dtype=torch.int64, device=dev)          # room for 131072 workgroups
+    if os.environ.get("PBE_STAMP_CFG"):                                  # force a tile config (| split << 8) for every spec
+        ops.tune(1, int(os.environ["PBE_STAMP_CFG"]))
     for spec in sys.argv[1:]:
         call, fl = make(spec)
         h.pbe_debug_set_stamps(None)
