@@ -230,7 +230,7 @@ int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_
 
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
- * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2).
+ * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1).
  */
 int pbe_tune(int32_t key, int32_t value);
 

@@ -69,7 +69,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
     // MODE 2 = 3x3 conv (stride 1, pad 1) with the activation HALO resident in LDS: a tile is BM pixels = whole image rows (or whole
     // images); for every 64-channel block its (rows + 2) x (width + 2) halo (HPA rows of 128 B, zero outside the image) is staged
@@ -315,74 +315,175 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         }
         PBE_STAMP(2);
         stage_svec();
-        int slot_rd = 0, slot_wr = D % S;
-        for (int blk = blk0; blk < blk1; ++blk) {
-            const unsigned char* ab = abuf + ((blk - blk0) & 1) * (HPA * 128);
-            const bool next_a = blk + 1 < blk1;
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {          // (not unrolled: 9 copies of the body cost registers and 30 000 lines of ISA)
-                const int kt = blk * 9 + tap;
-#ifdef PBE_STAMPS
-                if (kt == blk0 * 9 + 1) PBE_STAMP(3);
-#endif
-                // W(kt) must have landed.  Younger DMAs that may stay in flight: the later W tiles (D - 1, fewer at the end) and,
-                // at taps 1 .. D, the halo pieces of block blk + 1 (issued at tap 0 right after W(kt0 + D)).  The halo of THIS
-                // block is older than W(kt) (in-order vmcnt), so it has landed too.
-                const int wleft = min(nk2 - 1 - kt, D - 1);
-                const bool a_young = next_a && tap >= 1 && tap <= D;
-                if (a_young) {
-                    if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
-                    else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
-                    else wait_vmcnt<LAH>();
-                } else {
-                    if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW>();
-                    else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
-                    else wait_vmcnt<0>();
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const unsigned char* sw = wring + slot_rd * W_BYTES;
+        if constexpr (PP) {
+            // Ping-pong form (8 waves, two per SIMD).  With the halo resident a k-tile costs each wave 18 fragment reads, 2-3 weight
+            // DMAs and 40 MFMAs; in the plain loop both waves of a SIMD pass the barrier together, read LDS together (the LDS is
+            // the bottleneck for ~580 cycles) and then share the matrix pipe: 2 430 cycles per k-tile against 1 280 of MFMA work
+            // (profiles/r02_phase_stamps_halo_tiles.txt).  Here waves 0-3 and 4-7 alternate: in every half period one group
+            // reads its fragments while the other group's MFMAs own the pipe.
+            //   period i (tile kt), barriers b(2i-1) | b(2i) | b(2i+1):
+            //     start:        every wave issues W(kt + D) (and the next block's halo at tap 0)
+            //     first half:   group 0 reads tile kt's fragments      | group 1 runs the MFMAs of tile kt-1
+            //     second half:  group 0 runs the MFMAs of tile kt      | group 1 reads tile kt's fragments
+            //     end:          every wave retires ITS DMAs of tile kt+1 (counted vmcnt), lgkmcnt(0)
+            //   RAW: tile kt+1 is first read after b(2i+1), one barrier after every wave's wait.  WAR: the slot W(kt+1+D) lands in
+            //   (tile kt's) and the halo buffer of block blk-1 were last read before b(2i+1) / b(2i-1) (lgkmcnt(0) precedes both).
+            static_assert(NW == 8 && BOTH, "ping-pong needs two waves per SIMD and both k-steps' fragments in registers");
+            const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+            h16x8 fa[2][TM], fw[2][TN];
+            auto read_frags = [&](const unsigned char* ab, const unsigned char* sw, int tap) {
                 const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
                 const int shift = (trow - 1) * HW2 + (tap - 3 * trow - 1);
-                h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
-                int arow[TM];
 #pragma unroll
-                for (int j = 0; j < TM; ++j) arow[j] = hc[j] + shift;
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int ks = 0; ks < (BOTH ? 2 : 1); ++ks) {
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((ks * 4 + fq) ^ (arow[j] & 7)) << 4));
+                    for (int j = 0; j < TM; ++j) {
+                        const int ar = hc[j] + shift;
+                        fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + ar * 128 + (((ks * 4 + fq) ^ (ar & 7)) << 4));
+                    }
 #pragma unroll
                     for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + D < nk2) issue_w(kt + D, slot_wr);
-                if (tap == 0 && next_a) issue_a(blk + 1, (blk + 1 - blk0) & 1);
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mfmas = [&]() {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
-                if constexpr (!BOTH) {
+                    for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        fa[0][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((4 + fq) ^ (arow[j] & 7)) << 4));
-#pragma unroll
-                    for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ 64) + i * 16 * 128);
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
-                slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
-                slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+            };
+            // One R block and one M block in the code (three inlined copies of the MFMA block spilled 270 B per thread):
+            // both groups run  R(kt) | barrier | M(kt) | barrier,  group 1 one barrier late; what differs per group is only WHERE
+            // in that sequence a period's DMA issue and wait sit (period start = group 0's R start = group 1's M start).
+            if (blk0 < blk1) {
+                if (D >= 2) wait_vmcnt<(D - 1) * LW>(); else wait_vmcnt<0>();      // halo of block blk0 and W(kt0) landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int kt_first = blk0 * 9;
+                // the DMAs of the period whose tile is kt: W(kt + D) and, when kt opens a block, the next block's halo
+                auto issue_period = [&](int kt) {
+                    if (kt >= nk2) return;
+                    const int b = kt / 9, tp = kt - b * 9, i = kt - kt_first;
+                    if (kt + D < nk2) issue_w(kt + D, (i + D) % S);
+                    if (tp == 0 && b + 1 < blk1) issue_a(b + 1, (b + 1 - blk0) & 1);
+                };
+                // retire my DMAs of tile kt+1 at the end of period kt: later W tiles (kt+2 .. kt+D) and, at taps 0 .. D-1, the next
+                // block's halo pieces (issued after W(kt+1)) may stay in flight
+                auto wait_period = [&](int kt, int tap, bool next_a) {
+                    const int wleft = min(max(nk2 - 2 - kt, 0), D - 1);
+                    const bool a_young = next_a && tap <= D - 1;
+                    if (a_young) {
+                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
+                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
+                        else wait_vmcnt<LAH>();
+                    } else {
+                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW>();
+                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
+                        else wait_vmcnt<0>();
+                    }
+                };
+                if (grp == 1) {                            // the stagger: group 1 spends period 0's first half issuing only
+                    issue_period(kt_first);
+                    __builtin_amdgcn_s_barrier();
+                }
+                int slot_rd = 0, blk = blk0, tap = 0;
+                for (int kt = kt_first; kt < nk2; ++kt) {
+#ifdef PBE_STAMPS
+                    if (kt == kt_first + 1) PBE_STAMP(3);
+#endif
+                    const bool next_a = blk + 1 < blk1;
+                    if (grp == 0) issue_period(kt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(abuf + ((blk - blk0) & 1) * (HPA * 128), wring + slot_rd * W_BYTES, tap);
+                    if (grp == 1) wait_period(kt, tap, next_a);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    if (grp == 1) issue_period(kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas();
+                    if (grp == 0) wait_period(kt, tap, next_a);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+                    if (++tap == 9) { tap = 0; ++blk; }
+                }
+                if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last M phase
             }
-        }
+        } else {
+        int slot_rd = 0, slot_wr = D % S;
+            for (int blk = blk0; blk < blk1; ++blk) {
+                const unsigned char* ab = abuf + ((blk - blk0) & 1) * (HPA * 128);
+                const bool next_a = blk + 1 < blk1;
+    #pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {          // (not unrolled: 9 copies of the body cost registers and 30 000 lines of ISA)
+                    const int kt = blk * 9 + tap;
+    #ifdef PBE_STAMPS
+                    if (kt == blk0 * 9 + 1) PBE_STAMP(3);
+    #endif
+                    // W(kt) must have landed.  Younger DMAs that may stay in flight: the later W tiles (D - 1, fewer at the end) and,
+                    // at taps 1 .. D, the halo pieces of block blk + 1 (issued at tap 0 right after W(kt0 + D)).  The halo of THIS
+                    // block is older than W(kt) (in-order vmcnt), so it has landed too.
+                    const int wleft = min(nk2 - 1 - kt, D - 1);
+                    const bool a_young = next_a && tap >= 1 && tap <= D;
+                    if (a_young) {
+                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
+                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
+                        else wait_vmcnt<LAH>();
+                    } else {
+                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW>();
+                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
+                        else wait_vmcnt<0>();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const unsigned char* sw = wring + slot_rd * W_BYTES;
+                    const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+                    const int shift = (trow - 1) * HW2 + (tap - 3 * trow - 1);
+                    h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
+                    int arow[TM];
+    #pragma unroll
+                    for (int j = 0; j < TM; ++j) arow[j] = hc[j] + shift;
+    #pragma unroll
+                    for (int ks = 0; ks < (BOTH ? 2 : 1); ++ks) {
+    #pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((ks * 4 + fq) ^ (arow[j] & 7)) << 4));
+    #pragma unroll
+                        for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + D < nk2) issue_w(kt + D, slot_wr);
+                    if (tap == 0 && next_a) issue_a(blk + 1, (blk + 1 - blk0) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                    for (int i = 0; i < TN; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+                    if constexpr (!BOTH) {
+    #pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            fa[0][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((4 + fq) ^ (arow[j] & 7)) << 4));
+    #pragma unroll
+                        for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ 64) + i * 16 * 128);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < TN; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+                    slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+                }
+            }
+}
     } else {
     PBE_STAMP(1);                                    // loader state (+ tap table) ready
 #pragma unroll
@@ -783,21 +884,28 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     return best;
 }
 
-template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0>
+int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): ping-pong main loop of the halo-resident conv tiles
+
+template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
+    // (ping-pong only where a wave's MFMA phase - (BM/NWM/16) x (BN/NWN/16) x 2 MFMAs - is as long as its read phase: measured
+    //  25 % SLOWER on the 128x160 halo tile, whose 20 MFMAs cannot cover 14 fragment reads + 3 DMA issues)
+    if constexpr (MODE == 2 && !PP && (BM / NWM / 16) * (BN / NWN / 16) >= 16) {
+        if (g_pbe_pingpong) { launch_cfg<BM, BN, NWM, NWN, S, MODE, HPA, true>(p, batch, s); return; }
+    }
     constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 + 1024 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float);   // + svec[4][BN]
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;
     pbe_prof_begin(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     {   // algorithmic bytes: every operand once (fp16): activations, weights, output, fused residual
         const double nout = p.act == PBE_ACT_GEGLU ? p.N * 0.5 : (double)p.N;
         const double a_el = MODE != 0 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
@@ -843,6 +951,7 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 1) { g_pbe_force_cfg = (value >= 0 && (value & 255) < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
+    if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
