@@ -228,6 +228,18 @@ int pbe_image_post_f32(const void* src, float* dst, int32_t B, int32_t HW, int32
 int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t Hin, int32_t Win, int32_t Hout,
                             int32_t Wout, int32_t antialias, pbe_stream_t stream);
 
+/* Image I/O on the device (scripts/inference.py:305-322 pre-processing, :346-399 outputs; test_bench_dataset.py:74-99):
+ * pbe_u8_to_planes_f32     u8 HWC [B, H*W, C] -> fp32 CHW planes: (v/255 - mean[c]) / std[c]  (ToTensor + Normalize), or the mask
+ *                          forms binarize = 1: (1 - v/255) thresholded at 0.5 (inference.py:311-315), 2: 1 - v/255 (test bench);
+ * pbe_mul_planes_f32       out[b,c] = x[b,c] * m[b,0]                                  (inpaint_image = image * mask, :319);
+ * pbe_planes_to_u8_canvas  one CHW image -> a rectangle of a u8 HWC canvas: trunc(255 * clamp(x * a[c] + b[c], 0, 1)); the result /
+ *                          GT / inpaint / ref / mask files and the 4-tile grid (make_grid, pad 2) are such rectangles. */
+int pbe_u8_to_planes_f32(const void* src, float* dst, int32_t B, int32_t C, int32_t HW, const float* mean3, const float* std3,
+                         int32_t binarize, pbe_stream_t stream);
+int pbe_mul_planes_f32(const float* x, const float* m, float* out, int32_t B, int32_t C, int32_t HW, pbe_stream_t stream);
+int pbe_planes_to_u8_canvas(const float* src, void* canvas, int32_t H, int32_t W, int32_t Hc, int32_t Wc, int32_t y0, int32_t x0,
+                            const float* a3, const float* b3, int32_t bcast, pbe_stream_t stream);
+
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
  * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1).

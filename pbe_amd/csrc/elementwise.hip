@@ -342,3 +342,81 @@ extern "C" int pbe_resize_bilinear_f32(const float* src, float* dst, int32_t pla
     hipLaunchKernelGGL(resize_bilinear_kernel, EW_GRID(total), dim3(256), 0, s, src, dst, Hin, Win, Hout, Wout, sh, sw, antialias ? 1 : 0, total);
     EW_END(s, 4.0 * ((double)planes * Hin * Win + (double)total), "pbe_resize_bilinear_f32");
 }
+
+// ---- image I/O on the device (scripts/inference.py:305-322, 346-399) ---------------------------------
+// u8 pixels travel both ways; normalisation, masking, un-normalisation, clamp, the uint8 pack and the 4-tile grid run here.
+// pbe_u8_to_planes_f32: dst[b, c, y, x] = f(src[b, y, x, c] / 255) with f(v) = v * a[c] + b[c]   (ToTensor + Normalize)
+//                       or, with binarize = 1, f(v) = (1 - v) < 0.5 ? 0 : 1                      (inference.py:311-315 mask)
+//                       or, with binarize = 2, f(v) = 1 - v                                       (test_bench_dataset.py: not thresholded)
+// The float ops are the reference's, in its order (divide by 255, subtract mean, divide by std): (v - mean) / std, not an FMA.
+__global__ void u8_to_planes_kernel(const unsigned char* src, float* dst, int C, int HW, float m0, float m1, float m2, float s0, float s1, float s2,
+                                    int binarize, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // over B * HW pixels
+    if (i >= total) return;
+    const long b = i / HW, px = i - b * HW;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (int c = 0; c < C; ++c) {
+        float v = (float)src[i * C + c] / 255.0f;
+        if (binarize == 1) v = (1.0f - v) < 0.5f ? 0.0f : 1.0f;
+        else if (binarize == 2) v = 1.0f - v;
+        else { v = v - mean[c]; asm volatile("" : "+v"(v)); v = v / sd[c]; }
+        dst[(b * C + c) * HW + px] = v;
+    }
+}
+extern "C" int pbe_u8_to_planes_f32(const void* src, float* dst, int32_t B, int32_t C, int32_t HW, const float* mean3, const float* std3,
+                                    int32_t binarize, pbe_stream_t stream) {
+    PBE_REQUIRE(src && dst && B > 0 && (C == 1 || C == 3) && HW > 0, "pbe_u8_to_planes_f32: bad arguments");
+    PBE_REQUIRE(binarize || (mean3 && std3), "pbe_u8_to_planes_f32: mean / std needed");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * HW;
+    const float m[3] = {mean3 ? mean3[0] : 0.f, mean3 && C > 1 ? mean3[1] : 0.f, mean3 && C > 2 ? mean3[2] : 0.f};
+    const float d[3] = {std3 ? std3[0] : 1.f, std3 && C > 1 ? std3[1] : 1.f, std3 && C > 2 ? std3[2] : 1.f};
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(u8_to_planes_kernel, EW_GRID(total), dim3(256), 0, s, (const unsigned char*)src, dst, C, HW, m[0], m[1], m[2], d[0], d[1], d[2], binarize, total);
+    EW_END(s, (double)total * C * 5.0, "pbe_u8_to_planes_f32");
+}
+
+// pbe_mul_planes_f32: out[b, c, :] = x[b, c, :] * m[b, 0, :]   (inpaint_image = image * mask, inference.py:319)
+__global__ void mul_planes_kernel(const float* x, const float* m, float* out, int C, int HW, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // over B * C * HW
+    if (i >= total) return;
+    const long bc = i / HW, px = i - bc * HW, b = bc / C;
+    out[i] = x[i] * m[b * HW + px];
+}
+extern "C" int pbe_mul_planes_f32(const float* x, const float* m, float* out, int32_t B, int32_t C, int32_t HW, pbe_stream_t stream) {
+    PBE_REQUIRE(x && m && out && B > 0 && C > 0 && HW > 0, "pbe_mul_planes_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * C * HW;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(mul_planes_kernel, EW_GRID(total), dim3(256), 0, s, x, m, out, C, HW, total);
+    EW_END(s, (double)total * 12.0, "pbe_mul_planes_f32");
+}
+
+// pbe_planes_to_u8_canvas: canvas[y0 + y, x0 + x, c] = (uint8) trunc(255 * clamp(src[c, y, x] * a[c] + b[c], 0, 1))  for one CHW plane
+// set (src channel stride HW; `bcast` = 1 repeats channel 0 into the 3 output channels: the mask file).  Truncation, multiply THEN
+// add (two roundings), like the reference's `(255. * x.numpy()).astype(np.uint8)` after `x * std + mean` / `(x + 1) / 2`.
+__global__ void planes_to_canvas_kernel(const float* src, unsigned char* canvas, int H, int W, int Wc, int y0, int x0, float a0, float a1, float a2,
+                                        float b0, float b1, float b2, int bcast, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // over H * W pixels
+    if (i >= total) return;
+    const int y = (int)(i / W), x = (int)(i - (long)y * W);
+    const float a[3] = {a0, a1, a2}, b[3] = {b0, b1, b2};
+    unsigned char* d = canvas + ((long)(y0 + y) * Wc + (x0 + x)) * 3;
+    for (int c = 0; c < 3; ++c) {
+        float v = src[(long)(bcast ? 0 : c) * H * W + i] * a[c];
+        asm volatile("" : "+v"(v));
+        v = v + b[c];
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        d[c] = (unsigned char)(255.0f * v);
+    }
+}
+extern "C" int pbe_planes_to_u8_canvas(const float* src, void* canvas, int32_t H, int32_t W, int32_t Hc, int32_t Wc, int32_t y0, int32_t x0,
+                                       const float* a3, const float* b3, int32_t bcast, pbe_stream_t stream) {
+    PBE_REQUIRE(src && canvas && a3 && b3 && H > 0 && W > 0 && y0 >= 0 && x0 >= 0 && y0 + H <= Hc && x0 + W <= Wc, "pbe_planes_to_u8_canvas: tile outside the canvas");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)H * W;
+    EW_BEGIN(s);
+    hipLaunchKernelGGL(planes_to_canvas_kernel, EW_GRID(total), dim3(256), 0, s, src, (unsigned char*)canvas, H, W, Wc, y0, x0, a3[0], a3[1], a3[2], b3[0], b3[1],
+                       b3[2], bcast, total);
+    EW_END(s, (double)total * 15.0, "pbe_planes_to_u8_canvas");
+}

@@ -64,6 +64,9 @@ SYMBOLS = {
     "pbe_bcast_row_f16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "pbe_image_post_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "pbe_resize_bilinear_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "pbe_u8_to_planes_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(c_f32), C.POINTER(c_f32), c_i32, c_vp]),
+    "pbe_mul_planes_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "pbe_planes_to_u8_canvas": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(c_f32), C.POINTER(c_f32), c_i32, c_vp]),
     "pbe_tune": (c_i32, [c_i32, c_i32]),
     "pbe_prof_enable": (c_i32, [c_i32]),
     "pbe_prof_reset": (c_i32, []),

@@ -462,6 +462,44 @@ def resize_bilinear(x: torch.Tensor, size, antialias: bool = True) -> torch.Tens
     return y
 
 
+def u8_to_planes(src: torch.Tensor, mean=None, std=None, mask_mode: int = 0) -> torch.Tensor:
+    """uint8 [B, H, W, C] (C = 3) or [B, H, W] (mask) on the GPU -> fp32 [B, C, H, W]: (v/255 - mean) / std, or the mask forms
+    mask_mode 1: (1 - v/255) thresholded at 0.5 (scripts/inference.py:311-315), 2: 1 - v/255 (test_bench_dataset.py)."""
+    _req(src, torch.uint8, "u8_to_planes src")
+    src = src.contiguous()
+    if src.dim() == 3:
+        src = src.unsqueeze(-1)
+    B, H, W, Cc = src.shape
+    y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src.device)
+    m = (C.c_float * 3)(*(list(mean) + [0.0] * 3)[:3]) if mean is not None else None
+    sd = (C.c_float * 3)(*(list(std) + [1.0] * 3)[:3]) if std is not None else None
+    _l.check(_l.load().pbe_u8_to_planes_f32(_p(src), _p(y), B, Cc, H * W, m, sd, mask_mode, _stream()), "pbe_u8_to_planes_f32")
+    return y
+
+
+def mul_planes(x: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """x [B, C, H, W] * m [B, 1, H, W] (inpaint_image = image * mask)."""
+    _f(x, "mul_planes x"); _f(m, "mul_planes m")
+    x, m = x.contiguous(), m.contiguous()
+    B, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    _l.check(_l.load().pbe_mul_planes_f32(_p(x), _p(m), _p(y), B, Cc, H * W, _stream()), "pbe_mul_planes_f32")
+    return y
+
+
+def planes_to_canvas(src: torch.Tensor, canvas: torch.Tensor, y0: int, x0: int, a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0)) -> None:
+    """One fp32 [3, H, W] (or [1, H, W]: broadcast to 3 channels) image -> canvas[y0:y0+H, x0:x0+W, :] (uint8 [Hc, Wc, 3]) as
+    trunc(255 * clamp(x * a[c] + b[c], 0, 1))."""
+    _f(src, "planes_to_canvas src"); _req(canvas, torch.uint8, "planes_to_canvas canvas")
+    src = src.contiguous()
+    Cc, H, W = src.shape
+    if not canvas.is_contiguous() or canvas.dim() != 3 or canvas.shape[2] != 3 or Cc not in (1, 3):
+        raise _l.PbeError("planes_to_canvas: canvas must be a contiguous [Hc, Wc, 3] uint8 tensor, src [3 or 1, H, W]")
+    aa, bb = (C.c_float * 3)(*[float(v) for v in a]), (C.c_float * 3)(*[float(v) for v in b])
+    _l.check(_l.load().pbe_planes_to_u8_canvas(_p(src), _p(canvas), H, W, canvas.shape[0], canvas.shape[1], int(y0), int(x0), aa, bb, 1 if Cc == 1 else 0,
+                                               _stream()), "pbe_planes_to_u8_canvas")
+
+
 def bcast_row(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, B: int, y_bs: int) -> None:
     """out[bi * y_bs + c] = a[c] + b[c] for bi < B."""
     _h(a, "bcast_row a"); _h(b, "bcast_row b"); _h(out, "bcast_row out")

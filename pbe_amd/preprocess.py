@@ -35,6 +35,25 @@ def load_triple(image_path: str, mask_path: str, reference_path: str) -> Dict[st
     return {"image": img, "mask": mask, "inpaint": img * mask, "ref": ref}
 
 
+def load_triple_u8(image_path: str, mask_path: str, reference_path: str) -> Dict[str, np.ndarray]:
+    """Decode only (what travels to the GPU): image HWC u8, mask HW u8, exemplar PIL-resized to 224x224 HWC u8."""
+    return {"image": np.asarray(Image.open(image_path).convert("RGB"), dtype=np.uint8),
+            "mask": np.array(Image.open(mask_path).convert("L"), dtype=np.uint8),
+            "ref": np.asarray(Image.open(reference_path).convert("RGB").resize((224, 224)), dtype=np.uint8)}
+
+
+def load_triple_device(image_path: str, mask_path: str, reference_path: str, device) -> Dict[str, torch.Tensor]:
+    """load_triple with the arithmetic of scripts/inference.py:306-319 on the GPU (pbe_u8_to_planes_f32 / pbe_mul_planes_f32):
+    the triple travels as uint8; the returned fp32 tensors live on `device` and equal load_triple()'s bit for bit."""
+    from . import ops
+    u8 = load_triple_u8(image_path, mask_path, reference_path)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device)[None] for k, v in u8.items()}
+    img = ops.u8_to_planes(dev["image"], (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    ref = ops.u8_to_planes(dev["ref"], CLIP_MEAN, CLIP_STD)
+    mask = ops.u8_to_planes(dev["mask"], mask_mode=1)
+    return {"image": img, "mask": mask, "inpaint": ops.mul_planes(img, mask), "ref": ref}
+
+
 def un_norm(x: torch.Tensor) -> torch.Tensor:
     return (x + 1.0) / 2.0
 
@@ -74,4 +93,38 @@ def save_outputs(outdir: str, stem: str, seed: int, triple: Dict[str, torch.Tens
     _save(un_norm(image), paths["gt"])
     _save(un_norm(inpaint), paths["inpaint"])
     _save(un_norm_clip(ref_big), paths["ref"])
+    return paths
+
+
+def save_outputs_device(outdir: str, stem: str, seed: int, triple: Dict[str, torch.Tensor], result: torch.Tensor, H: int, W: int) -> Dict[str, str]:
+    """save_outputs with the pixels composed on the GPU: the exemplar's bilinear resize, every
+    un-normalisation, clamp, the uint8 pack and the 4-tile grid are HIP kernels (pbe_resize_bilinear_f32, pbe_planes_to_u8_canvas);
+    one uint8 canvas comes back and the host only PNG-encodes.  Byte-identical files to save_outputs()."""
+    from . import ops
+    src, res, grid = (os.path.join(outdir, d) for d in ("source", "results", "grid"))
+    for d in (src, res, grid):
+        os.makedirs(d, exist_ok=True)
+    dev = result.device
+    image, inpaint, ref, mask = (triple[k][0].float() for k in ("image", "inpaint", "ref", "mask"))
+    ref_big = ops.resize_bilinear(ref[None], (H, W), True)[0]
+    pad = 2
+    # one canvas: the grid on top, then the five single images side by side below it
+    Wg = 4 * (W + pad) + pad
+    canvas = torch.zeros((H + 2 * pad + H, max(Wg, 5 * W), 3), dtype=torch.uint8, device=dev)
+    half, clip_a, clip_b = ((0.5,) * 3, (0.5,) * 3), CLIP_STD, CLIP_MEAN
+    tiles = [(image, *half), (inpaint, *half), (ref_big, clip_a, clip_b), (result.float(), (1.0,) * 3, (0.0,) * 3)]
+    for i, (t, a, b) in enumerate(tiles):
+        ops.planes_to_canvas(t, canvas, pad, pad + i * (W + pad), a, b)
+    y1 = H + 2 * pad
+    singles = [("result", result.float(), (1.0,) * 3, (0.0,) * 3), ("mask", mask, *half), ("gt", image, *half), ("inpaint", inpaint, *half),
+               ("ref", ref_big, clip_a, clip_b)]
+    for i, (_, t, a, b) in enumerate(singles):
+        ops.planes_to_canvas(t, canvas, y1, i * W, a, b)
+    host = canvas.cpu().numpy()
+    paths = {"grid": os.path.join(grid, f"grid-{stem}_{seed}.png"), "result": os.path.join(res, f"{stem}_{seed}.png"),
+             "mask": os.path.join(src, f"{stem}_{seed}_mask.png"), "gt": os.path.join(src, f"{stem}_{seed}_GT.png"),
+             "inpaint": os.path.join(src, f"{stem}_{seed}_inpaint.png"), "ref": os.path.join(src, f"{stem}_{seed}_ref.png")}
+    Image.fromarray(np.ascontiguousarray(host[:y1, :Wg])).save(paths["grid"])
+    for i, (name, *_rest) in enumerate(singles):
+        Image.fromarray(np.ascontiguousarray(host[y1:y1 + H, i * W:(i + 1) * W])).save(paths[name])
     return paths

@@ -138,18 +138,21 @@ def write_item(outdir: str, stem: str, image_u8: np.ndarray, mask_u8: np.ndarray
 
 def device_preprocess(img_u8: torch.Tensor, ref_u8: torch.Tensor, mask_u8: torch.Tensor) -> Dict[str, torch.Tensor]:
     """uint8 batches already on the GPU ([B,H,W,3], [B,224,224,3], [B,H,W]) -> the float tensors of the reference's
-    dataset item, batched: image [-1,1], mask = 1 - L/255, ref CLIP-normalised (test_bench_dataset.py:74-99)."""
-    dev = img_u8.device
-    image = (img_u8.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
-    ref = ref_u8.permute(0, 3, 1, 2).float() / 255.0
-    ref = (ref - torch.tensor(CLIP_MEAN, device=dev)[None, :, None, None]) / torch.tensor(CLIP_STD, device=dev)[None, :, None, None]
-    mask = 1 - mask_u8[:, None].float() / 255.0
-    return {"image": image, "mask": mask, "ref": ref}
+    dataset item, batched: image [-1,1], mask = 1 - L/255, ref CLIP-normalised (test_bench_dataset.py:74-99), by the HIP kernel
+    pbe_u8_to_planes_f32 (same float operations in the same order as ToTensor + Normalize)."""
+    from . import ops
+    return {"image": ops.u8_to_planes(img_u8, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)), "mask": ops.u8_to_planes(mask_u8, mask_mode=2),
+            "ref": ops.u8_to_planes(ref_u8, CLIP_MEAN, CLIP_STD)}
 
 
 def device_pack_u8(img01: torch.Tensor) -> torch.Tensor:
-    """[B,3,H,W] float in [0,1] on the GPU -> [B,H,W,3] uint8 (truncation, like ``(255 * x).astype(uint8)``)."""
-    return (img01 * 255.0).permute(0, 2, 3, 1).to(torch.uint8).contiguous()
+    """[B,3,H,W] float in [0,1] on the GPU -> [B,H,W,3] uint8 (truncation, like ``(255 * x).astype(uint8)``): pbe_planes_to_u8_canvas."""
+    from . import ops
+    B, _, H, W = img01.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=img01.device)
+    for b in range(B):
+        ops.planes_to_canvas(img01[b].float(), out[b], 0, 0)
+    return out
 
 
 def iter_loaded(ds: COCOImageDataset, batches, pool: cf.ThreadPoolExecutor) -> Iterator[Tuple[int, List[tuple]]]:

@@ -48,6 +48,8 @@ def parse(argv=None):
     p.add_argument("--mask_path", type=str, default="")
     p.add_argument("--reference_path", type=str, default="")
     p.add_argument("--random_weights", action="store_true", help="name-seeded random weights instead of --ckpt")
+    p.add_argument("--dump_tensors", type=str, default="", help="(not in the reference) save the start code, the posterior noise and the "
+                   "intermediate tensors of this run to an .npz: what a CPU replay needs to reproduce the run without the device RNG")
     return p.parse_args(argv)
 
 
@@ -88,23 +90,32 @@ def main(argv=None):
         start_code = torch.randn([opt.n_samples, opt.C, opt.H // opt.f, opt.W // opt.f], device=device)
 
     with torch.no_grad(), model.ema_scope():
-        t = preprocess.load_triple(opt.image_path, opt.mask_path, opt.reference_path)
+        t = preprocess.load_triple_device(opt.image_path, opt.mask_path, opt.reference_path, device)      # uint8 up, arithmetic on the GPU
         filename = os.path.basename(opt.image_path)
-        test_model_kwargs = {"inpaint_mask": t["mask"].to(device), "inpaint_image": t["inpaint"].to(device)}
-        ref = t["ref"].to(device)
+        test_model_kwargs = {"inpaint_mask": t["mask"], "inpaint_image": t["inpaint"]}
+        ref = t["ref"]
         uc = model.learnable_vector if opt.scale != 1.0 else None
         c = model.proj_out(model.get_learned_conditioning(ref))                      # scripts/inference.py:326-327
-        z_inpaint = model.get_first_stage_encoding(model.encode_first_stage(test_model_kwargs["inpaint_image"]))
+        post = model.encode_first_stage(test_model_kwargs["inpaint_image"])
+        pb, ph, pw, _ = post.parameters.shape
+        post_eps = torch.randn((pb, post.z, ph, pw)) if opt.dump_tensors else None   # the CPU draw DiagonalGaussianDistribution.sample() makes itself
+        z_inpaint = model.get_first_stage_encoding(post, noise=None if post_eps is None else post_eps.to(device))
         test_model_kwargs["inpaint_image"] = z_inpaint
         test_model_kwargs["inpaint_mask"] = pipeline.resize_mask(test_model_kwargs["inpaint_mask"], z_inpaint.shape[-2:])
         shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
         samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=opt.n_samples, shape=shape, verbose=False,
                                     unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta,
                                     x_T=start_code, test_model_kwargs=test_model_kwargs)
-        x = ops.image_post(model.decode_first_stage_nhwc(samples)).cpu()              # clamp((x+1)/2, 0, 1)
+        xd = ops.image_post(model.decode_first_stage_nhwc(samples))                  # clamp((x+1)/2, 0, 1), still on the GPU
         if not opt.skip_save:
-            for i in range(x.shape[0]):
-                paths = preprocess.save_outputs(opt.outdir, filename[:-4], opt.seed, t, x[i], opt.H, opt.W)
+            for i in range(xd.shape[0]):
+                paths = preprocess.save_outputs_device(opt.outdir, filename[:-4], opt.seed, t, xd[i], opt.H, opt.W)
+        x = xd.cpu()
+        if opt.dump_tensors:
+            import numpy as np
+            np.savez(opt.dump_tensors, x_T=(start_code if start_code is not None else torch.zeros(0)).float().cpu().numpy(),
+                     post_eps=post_eps.numpy(), c=c.float().cpu().numpy(), z_inpaint=z_inpaint.float().cpu().numpy(),
+                     mask64=test_model_kwargs["inpaint_mask"].float().cpu().numpy(), latent=samples.float().cpu().numpy(), image=x.numpy())
     print(f"Your samples are ready and waiting for you here: \n{opt.outdir} \n \nEnjoy.")
     return x
 

@@ -329,22 +329,81 @@ def test_full_unet_768_latents_and_batch32(dev, full):
         check("U-Net batch 32: sample 17 vs alone", yb[17:18], full.apply_model(xb[17:18], tb[17:18], cb[17:18]).float().cpu(), 2e-3)
 
 
-def test_inference_cli_on_bundled_example(dev, golden_dir, tmp_path):
-    """scripts/inference.py counterpart end to end on examples/example_1 (BASELINE config #1 inputs; seed 321,
-    scale 5 as in the reference's test.sh) with name-seeded weights, 4 PLMS steps: files written, image finite."""
+def _load_cli():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("pbe_inference_cli", os.path.join(root, "scripts", "inference.py"))
     cli = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cli)
+    return cli, root
+
+
+def test_inference_cli_on_bundled_example(dev, golden_dir, tmp_path):
+    """scripts/inference.py counterpart end to end on examples/example_1 at configs/v1.yaml size (BASELINE configs[0] inputs; seed 321,
+    scale 5 as in the reference's test.sh) with name-seeded weights, 4 PLMS steps: files written, image finite, and the files the
+    GPU composed (pbe_planes_to_u8_canvas) are byte-identical to the host composition of the same tensors."""
+    from PIL import Image
+    from pbe_amd import preprocess
+    cli, root = _load_cli()
     d = os.path.join(golden_dir, "examples")
+    paths = (os.path.join(d, "image_example_1.png"), os.path.join(d, "mask_example_1.png"), os.path.join(d, "reference_example_1.jpg"))
     out = cli.main(["--plms", "--outdir", str(tmp_path), "--config", os.path.join(root, "configs", "v1.yaml"), "--ddim_steps", "4",
-                    "--image_path", os.path.join(d, "image_example_1.png"), "--mask_path", os.path.join(d, "mask_example_1.png"),
-                    "--reference_path", os.path.join(d, "reference_example_1.jpg"), "--seed", "321", "--scale", "5", "--fixed_code"])
+                    "--image_path", paths[0], "--mask_path", paths[1], "--reference_path", paths[2], "--seed", "321", "--scale", "5", "--fixed_code"])
     assert out.shape == (1, 3, 512, 512) and torch.isfinite(out).all() and 0 <= out.min() and out.max() <= 1
-    for sub, name in (("results", "image_example_1_321.png"), ("grid", "grid-image_example_1_321.png"), ("source", "image_example_1_321_mask.png"),
-                      ("source", "image_example_1_321_GT.png"), ("source", "image_example_1_321_inpaint.png"), ("source", "image_example_1_321_ref.png")):
-        assert os.path.getsize(os.path.join(str(tmp_path), sub, name)) > 0
+    names = {"result": ("results", "image_example_1_321.png"), "grid": ("grid", "grid-image_example_1_321.png"), "mask": ("source", "image_example_1_321_mask.png"),
+             "gt": ("source", "image_example_1_321_GT.png"), "inpaint": ("source", "image_example_1_321_inpaint.png"), "ref": ("source", "image_example_1_321_ref.png")}
+    host_dir = str(tmp_path / "host")
+    host = preprocess.save_outputs(host_dir, "image_example_1", 321, preprocess.load_triple(*paths), out[0], 512, 512)
+    for k, (sub, name) in names.items():
+        f = os.path.join(str(tmp_path), sub, name)
+        assert os.path.getsize(f) > 0
+        a, b = np.asarray(Image.open(f)), np.asarray(Image.open(host[k]))
+        assert a.shape == b.shape and np.array_equal(a, b), f"{k}: GPU-composed file differs from the host composition in {int((a != b).sum())} bytes"
+    # device pre-processing == host pre-processing, bit for bit
+    td, th = preprocess.load_triple_device(*paths, dev), preprocess.load_triple(*paths)
+    for k in ("image", "mask", "inpaint", "ref"):
+        assert torch.equal(td[k].cpu(), th[k]), k
+
+
+@pytest.mark.parametrize("example,seed,steps", [(1, 321, 4), (2, 5876, 2), (3, 5065, 2)])
+def test_inference_cli_matches_oracle_pipeline(dev, golden_dir, tmp_path, example, seed, steps):
+    """The CLI's RESULT IMAGE against the oracle's statement of scripts/inference.py:305-348 on the reference's three bundled triples
+    (test.sh:1-29: seeds 321 / 5876 / 5065, --scale 5, --plms).  Narrow-topology weights keep the CPU oracle in seconds; the run's
+    device-RNG start code and the posterior noise are handed to the oracle through --dump_tensors.  Tolerances: the per-stage bounds
+    of the module docstring (conditioning / latent 4e-3 / 8e-3 after <= 5 U-Net calls), <= 1 grey level mean on the PNG."""
+    import yaml
+    from PIL import Image
+    from oracle_loader import O
+    cli, root = _load_cli()
+    d = os.path.join(golden_dir, "examples")
+    paths = (os.path.join(d, f"image_example_{example}.png"), os.path.join(d, f"mask_example_{example}.png"), os.path.join(d, f"reference_example_{example}.jpg"))
+    cfg = str(tmp_path / "narrow.yaml")
+    with open(cfg, "w") as f:
+        yaml.safe_dump({"model": build.narrow_config()}, f)
+    dump = str(tmp_path / "dump.npz")
+    out = cli.main(["--plms", "--outdir", str(tmp_path), "--config", cfg, "--ddim_steps", str(steps), "--image_path", paths[0], "--mask_path", paths[1],
+                    "--reference_path", paths[2], "--seed", str(seed), "--scale", "5", "--fixed_code", "--random_weights", "--dump_tensors", dump])
+    t = np.load(dump)
+    img = np.asarray(Image.open(paths[0]).convert("RGB"))
+    msk = np.asarray(Image.open(paths[1]).convert("L"))
+    ref = np.asarray(Image.open(paths[2]).convert("RGB").resize((224, 224)))
+    oi, _, om, oref = O.preprocess_triple(img, msk, ref)
+    model = build.narrow_model("cpu")
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.inpaint_pipeline(sd, oi, om, oref, torch.from_numpy(t["x_T"]), torch.from_numpy(t["post_eps"]), S=steps, scale=5.0, unet_cfg=cases.UNET_NARROW,
+                                  vae_cfg=cases.VAE_NARROW, clip_cfg=cases.CLIP_NARROW, map_cfg=cases.MAPPER_NARROW)
+    assert want["calls"] == steps + 1
+    check(f"CLI example_{example}: conditioning c", torch.from_numpy(t["c"]), want["c"], 4e-3)
+    check(f"CLI example_{example}: z_inpaint", torch.from_numpy(t["z_inpaint"]), want["z_inpaint"], 4e-3)
+    assert np.abs(t["mask64"] - want["mask64"].numpy()).max() <= 2e-6
+    check(f"CLI example_{example}: final latent ({steps} PLMS steps)", torch.from_numpy(t["latent"]), want["latent"], 8e-3)
+    png = np.asarray(Image.open(os.path.join(str(tmp_path), "results", f"image_example_{example}_{seed}.png"))).astype(np.float32)
+    exp = (255.0 * want["image"][0].permute(1, 2, 0).numpy()).astype(np.uint8).astype(np.float32)
+    mad = float(np.abs(png - exp).mean())
+    report(f"CLI example_{example}: result PNG vs oracle, mean |d| in grey levels", mad, 1.0)
+    assert png.shape == (512, 512, 3) and mad <= 1.0
+    assert torch.equal(out, torch.from_numpy(t["image"]))
 
 
 # ---- checkpoint FILES through the product loader (SURVEY.md §8 f-2; scripts/inference.py:58-75, ddpm.py:245-260) --------

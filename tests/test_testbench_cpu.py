@@ -59,16 +59,17 @@ def test_dataset_item_layout_and_formulas(tmp_path):
     assert torch.allclose(kw["ref_imgs"][0], torch.from_numpy(ref).permute(2, 0, 1), atol=1e-6)
 
 
-def test_device_preprocess_matches_dataset_items(tmp_path):
+def test_device_preprocess_has_no_cpu_fallback(tmp_path):
+    """device_preprocess / device_pack_u8 are HIP kernels (pbe_u8_to_planes_f32, pbe_planes_to_u8_canvas): CPU tensors are refused.
+    Their equality with the dataset items is tested on the GPU (tests/test_testbench_gpu.py)."""
+    from pbe_amd.lib import PbeError
     ds = tb.COCOImageDataset(make_bench(str(tmp_path)))
-    items = [ds.load_uint8(i) for i in range(3)]
-    t = tb.device_preprocess(torch.from_numpy(np.stack([x[0] for x in items])), torch.from_numpy(np.stack([x[1] for x in items])),
+    items = [ds.load_uint8(i) for i in range(2)]
+    with pytest.raises(PbeError):
+        tb.device_preprocess(torch.from_numpy(np.stack([x[0] for x in items])), torch.from_numpy(np.stack([x[1] for x in items])),
                              torch.from_numpy(np.stack([x[2] for x in items])))
-    for i in range(3):
-        image, kw, _ = ds[i]
-        assert torch.allclose(t["image"][i], image) and torch.allclose(t["mask"][i], kw["inpaint_mask"])
-        assert torch.allclose(t["ref"][i], kw["ref_imgs"][0], atol=1e-6)
-        assert torch.allclose(t["image"][i] * t["mask"][i], kw["inpaint_image"])
+    with pytest.raises(PbeError):
+        tb.device_pack_u8(torch.rand(1, 3, 8, 8))
 
 
 def test_rank_batches_drop_last_and_partition():

@@ -51,3 +51,20 @@ def test_sweep_matches_oracle_and_is_rank_invariant(dev, tmp_path):
         exp = (255.0 * want[k].permute(1, 2, 0).numpy()).astype(np.uint8).astype(np.int32)
         d = np.abs(got - exp)
         assert d.mean() <= 1.5 and np.percentile(d, 99) <= 8, (d.mean(), d.max())      # fp16 path vs fp32 oracle after 5 U-Net calls, in 8-bit levels
+
+
+def test_device_preprocess_matches_dataset_items(dev, tmp_path):
+    """uint8 up, normalisation on the GPU (pbe_u8_to_planes_f32): equal, bit for bit, to the float tensors of the reference-shaped
+    dataset item (test_bench_dataset.py:74-99); the uint8 pack (pbe_planes_to_u8_canvas) equals `(255 * x).astype(uint8)`."""
+    ds = tb.COCOImageDataset(make_bench(str(tmp_path)))
+    items = [ds.load_uint8(i) for i in range(3)]
+    t = tb.device_preprocess(torch.from_numpy(np.stack([x[0] for x in items])).to(dev), torch.from_numpy(np.stack([x[1] for x in items])).to(dev),
+                             torch.from_numpy(np.stack([x[2] for x in items])).to(dev))
+    for i in range(3):
+        image, kw, _ = ds[i]
+        assert torch.equal(t["image"][i].cpu(), image) and torch.equal(t["mask"][i].cpu(), kw["inpaint_mask"])
+        assert torch.equal(t["ref"][i].cpu(), kw["ref_imgs"][0])
+    x = torch.rand(2, 3, 40, 56, generator=torch.Generator().manual_seed(1))
+    x[0, :, 0, :8] = torch.tensor([0.0, 1.0, 0.5, 1.0 / 255, 254.999 / 255, 0.999999, 1e-8, 0.25])
+    got = tb.device_pack_u8(x.to(dev)).cpu().numpy()
+    assert np.array_equal(got, (255.0 * x.permute(0, 2, 3, 1).numpy()).astype(np.uint8))
