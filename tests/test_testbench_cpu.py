@@ -5,6 +5,7 @@ import importlib.util
 import os
 
 import numpy as np
+import pytest
 import torch
 from PIL import Image
 
