@@ -42,6 +42,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE config #2: 4)")
     ap.add_argument("--plms-steps", type=int, default=50)
     ap.add_argument("--scale", type=float, default=5.0)
+    ap.add_argument("--image-size", type=int, default=512, choices=(512, 768), help="768 = BASELINE configs[4] geometry (96x96 latents)")
+    ap.add_argument("--precision", default="fp16", choices=("fp16", "fp8"),
+                    help="fp8 = BASELINE configs[4]: e4m3 operands for the LayerNorm-fed projections (pbe_amd.precision); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -247,8 +250,11 @@ def main():
     from pbe_amd.shard import gather_images
 
     model, cpu_sd = build_model(device, rank, world)
+    if a.precision == "fp8":
+        from pbe_amd.precision import set_linear_precision
+        set_linear_precision(model, "fp8")
     B = a.batch
-    inp = {k: v.to(device) for k, v in cases.synthetic_triples(B, 512, first_index=rank * B).items()}      # resident in HBM
+    inp = {k: v.to(device) for k, v in cases.synthetic_triples(B, a.image_size, first_index=rank * B).items()}      # resident in HBM
 
     def one_step(timings=None):
         out = inpaint(model, inp["image"], inp["mask"], inp["ref"], steps=a.plms_steps, scale=a.scale, x_T=inp["x_T"],
@@ -295,18 +301,30 @@ def main():
 
     images = world * B * a.steps
     value = images / elapsed
+    headline = a.image_size == 512 and a.precision == "fp16" and a.plms_steps == 50
+    # algorithmic FLOP per image (FlopCounterMode on the reference modules): U-Net forward per sample 796.94 GF at
+    # 64x64 latents, 2137.5 GF at 96x96; VAE encode + decode 3631.2 GF at 512x512 (x2.25 at 768x768); CLIP + mapper 155.6 GF
+    unet_gf = 796.94 if a.image_size == 512 else 2137.5
+    flop_per_image = ((a.plms_steps + 1) * 2 * unet_gf + 3631.2 * (1.0 if a.image_size == 512 else 2.25) + 155.6) * 1e9
+    lat = a.image_size // 8
+    if headline:
+        workload = ("BASELINE configs[1]: batch=4/GPU, 512x512, 50 PLMS steps (51 U-Net calls at batch 8), scale=5, fp16 "
+                    "activations + fp32 accumulate, name-seeded random-init U-Net + VAE + CLIP ViT-L/14 weights; the "
+                    "context-independent prefix of each guidance pair (first ResBlock + first self-attention) is evaluated once")
+    else:
+        workload = (f"batch={B}/GPU, {a.image_size}x{a.image_size} ({lat}x{lat} latents), {a.plms_steps} PLMS steps ({a.plms_steps + 1} U-Net calls at batch "
+                    f"{2 * B}), scale={a.scale:g}, " + ("e4m3 operands for the LayerNorm-fed projections (q|k, V^T, GEGLU) + fp16 elsewhere, fp32 accumulate"
+                                                        if a.precision == "fp8" else "fp16 activations + fp32 accumulate")
+                    + ", name-seeded random-init weights" + ("; BASELINE configs[4] geometry" if a.image_size == 768 else ""))
     line = {
-        "metric": "512x512 images/sec @50 PLMS steps scale=5", "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batch=4/GPU, 512x512, 50 PLMS steps (51 U-Net calls at batch 8), scale=5, fp16 "
-                               "activations + fp32 accumulate, name-seeded random-init U-Net + VAE + CLIP ViT-L/14 weights; the "
-                               "context-independent prefix of each guidance pair (first ResBlock + first self-attention) is evaluated once",
-                   "per_gpu_batch": B, "global_batch": world * B, "plms_steps": a.plms_steps, "cfg_scale": a.scale,
+        "metric": f"{a.image_size}x{a.image_size} images/sec @{a.plms_steps} PLMS steps scale={a.scale:g}", "value": value, "unit": "images/sec", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp16" if a.precision == "fp16" else "fp8 (e4m3 linear operands) + fp16", "data": "synthetic",
+        "config": {"workload": workload, "per_gpu_batch": B, "global_batch": world * B, "plms_steps": a.plms_steps, "cfg_scale": a.scale,
                    "parallelism": f"batch-sharded x{world}, no per-step collective"},
         "unet_ms_per_step_per_image": stage.get("sampler_ms", 0.0) / a.plms_steps / B,
         "stage_ms_per_batch": stage,
-        "e2e_mfma_frac": value / world * FLOP_PER_IMAGE / (MFMA_PEAK_TFLOPS * 1e12),
+        "e2e_mfma_frac": value / world * flop_per_image / (MFMA_PEAK_TFLOPS * 1e12),
     }
     if prof:
         MFMA = ("conv3x3_igemm", "gemm", "attention")
@@ -338,7 +356,7 @@ def main():
                             "avg_launch_us": d["avg_launch_us"], "avg_gflop_per_launch": d["gflop_per_launch"],
                             "frac_of_binding_roofline": d["frac_of_binding_roofline"], "classes": classes}
         line["kernel_classes"] = {k: {"launches": v["launches"], "ms": v["ms"], "rate": v["achieved"], "rate_unit": v["unit"]} for k, v in classes.items()}
-    if world == 1 and not a.no_cpu_baseline and cpu_sd is not None:
+    if world == 1 and not a.no_cpu_baseline and cpu_sd is not None and headline:
         try:
             line["cpu_baseline"] = cpu_baseline(cpu_sd, max(1, min(16, os.cpu_count() or 1)))     # a 1-GPU box owns a 16-core share of the host
         except Exception as e:                                              # noqa: BLE001

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 5
+#define PBE_ABI_VERSION 6
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -42,6 +42,9 @@ extern "C" {
 #define PBE_ACT_GELU_ERF 2
 #define PBE_ACT_QUICK_GELU 3
 #define PBE_ACT_GEGLU 4 /* GEMM only: W rows interleaved (x_j, gate_j); C[m, j] = x_j * gelu_erf(gate_j), width N/2 (attention.py:43-45) */
+
+#define PBE_DTYPE_F16 0
+#define PBE_DTYPE_F8E4M3 1 /* OCP e4m3fn (gfx950's fp8; not the fnuz form of gfx942) */
 
 typedef void* pbe_stream_t; /* hipStream_t */
 
@@ -80,6 +83,14 @@ typedef struct pbe_gemm_desc {
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
     int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..14; 10..14 are the halo-resident conv tiles and apply to stride-1 3x3 convs only) | (split-K factor << 8), factor 0 = library's choice */
+    /* fp8 operands (BASELINE configs[4]): operand_dtype = PBE_DTYPE_F8E4M3 -> A [M, K] and W [N, K] hold OCP e4m3 bytes, lda / ldw /
+     * strideA / strideW count BYTES (multiples of 16, K % 16 == 0, no A2), and C = act(alpha * a_scale[m] * w_scale[n] * sum_k A W + ...):
+     * a_scale fp32 [M] per row of A (e.g. per token, from pbe_layernorm_f8), w_scale fp32 [N] per row of W (per output channel, from the
+     * pack); *_scale_stride = elements between the batches' scale vectors (0: shared).  C, bias, rowvec, resid stay as in the fp16 form. */
+    const float* a_scale;
+    const float* w_scale;
+    int64_t a_scale_stride, w_scale_stride;
+    int32_t operand_dtype;  /* PBE_DTYPE_F16 (0) or PBE_DTYPE_F8E4M3 (1) */
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 /* Plan / workspace query for the SAME descriptor (nothing is launched): out6 = {tile config index, split-K factor,
@@ -141,6 +152,12 @@ int pbe_groupnorm_f16(const void* X, const void* X2, const float* gamma, const f
  * Replaces attention.py:240-242 (norm1/3), xf.py:22-28, HF CLIP layer norms. */
 int pbe_layernorm_f16(const void* X, const float* gamma, const float* beta, void* Y, int64_t rows,
                       int32_t C, int64_t ldx, int64_t ldy, float eps, pbe_stream_t stream);
+
+/* pbe_layernorm_f8 — the same LayerNorm emitting OCP e4m3 bytes and one fp32 scale per row (BASELINE configs[4]):
+ * Y[r, :] = e4m3(LN(X[r, :]) / row_scale[r]), row_scale[r] = max|LN(X[r, :])| / 448; ldy in bytes (multiple of 16).  Feeds the fp8
+ * operand form of pbe_gemm_f16 (A = Y, a_scale = row_scale). */
+int pbe_layernorm_f8(const void* X, const float* gamma, const float* beta, void* Y, float* row_scale, int64_t rows,
+                     int32_t C, int64_t ldx, int64_t ldy, float eps, pbe_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pbe_attention_f16 — fused softmax(Q K^T * scale) V (flash-style, no [N,N] tensor in HBM).

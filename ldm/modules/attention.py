@@ -54,11 +54,18 @@ class GEGLU(HipModule):
 
     def _pack(self):
         wi, bi = ops.pack_geglu(self.proj.weight.detach(), self.proj.bias.detach())
-        return SimpleNamespace(w=wi, b=bi)          # (value, gate) rows interleaved: gating fused in the GEMM epilogue
+        return SimpleNamespace(w=wi, b=bi, f8=None)          # (value, gate) rows interleaved: gating fused in the GEMM epilogue
 
     def run(self, x2d):
         p = self.pk()
         return ops.gemm(x2d, p.w, p.b, act=ops.ACT_GEGLU)
+
+    def run_f8(self, x8, sx):
+        """x8 / sx: the fp8 LayerNorm output and its row scales -> same result shape as run(); weights e4m3 with a scale per (interleaved) row."""
+        p = self.pk()
+        if p.f8 is None:
+            p.f8 = ops.pack_linear_f8(p.w.float())
+        return ops.gemm_f8(x8, sx, p.f8[0], p.f8[1], p.b, act=ops.ACT_GEGLU)
 
     def forward(self, x):
         x = _tokens(x)
@@ -81,6 +88,12 @@ class FeedForward(HipModule):
         """x2d [M, C] fp16 -> Linear(GEGLU(x)) (+ resid)."""
         p = self.pk()
         return ops.gemm(self.net[0].run(x2d), p.w2, p.b2, resid=resid)
+
+    def run_f8(self, x8, sx, resid=None):
+        """fp8 operands for the GEGLU projection (its input comes from the fp8 LayerNorm); the output projection stays fp16: its input
+        is the GEGLU product, whose per-row scale would need a pass over all 4C columns of a row."""
+        p = self.pk()
+        return ops.gemm(self.net[0].run_f8(x8, sx), p.w2, p.b2, resid=resid)
 
     def forward(self, x):
         x = _tokens(x)
@@ -106,7 +119,24 @@ class CrossAttention(HipModule):
         if self.to_q.weight.shape[1] == self.to_k.weight.shape[1]:
             ns.wqk = ops.pack_linear(torch.cat([self.to_q.weight, self.to_k.weight], 0))
         ns.wq, ns.wk = ops.pack_linear(self.to_q.weight), ops.pack_linear(self.to_k.weight)
+        ns.f8 = None
         return ns
+
+    def self_attention_f8(self, x8, sx, B, N):
+        """self_attention with fp8 (e4m3) operands for the q|k and V^T projections: x8 [B*N, C] uint8 + row scales sx [B*N] from
+        pbe_layernorm_f8, weights e4m3 with one scale per output channel.  The attention core itself stays fp16 (fp32 softmax)."""
+        p = self.pk()
+        if p.f8 is None:
+            p.f8 = (ops.pack_linear_f8(torch.cat([self.to_q.weight, self.to_k.weight], 0)), ops.pack_linear_f8(self.to_v.weight))
+        (wqk8, sqk), (wv8, sv) = p.f8
+        inner = self.heads * self.dim_head
+        qk = ops.gemm_f8(x8, sx, wqk8, sqk)
+        npad = (N + 7) // 8 * 8
+        vt = torch.empty((B, inner, npad), dtype=torch.float16, device=x8.device)
+        ops.gemm_f8(wv8.unsqueeze(0).expand(B, -1, -1), sv, x8.view(B, N, -1), sx.view(B, N), out=vt[:, :, :N] if npad != N else vt)
+        o = ops.attention(qk, qk[:, inner:], vt, B, self.heads, N, N, self.dim_head, self.scale,
+                          q_strides=(N * 2 * inner, 2 * inner), k_strides=(N * 2 * inner, 2 * inner), vt_strides=(inner * npad, npad))
+        return o.view(B * N, inner)
 
     # ---- fast paths used by BasicTransformerBlock -------------------------------------------
     def self_attention(self, xn, B, N):
@@ -170,11 +200,17 @@ class BasicTransformerBlock(HipModule):
         return SimpleNamespace(g1=f32(self.norm1.weight), b1=f32(self.norm1.bias), g3=f32(self.norm3.weight), b3=f32(self.norm3.bias),
                                eps1=self.norm1.eps, eps3=self.norm3.eps)
 
+    linear_fp8 = False          # pbe_amd.precision.set_linear_precision(model, "fp8") turns the LayerNorm-fed projections to e4m3 operands
+
     def run(self, x2d, B, N, ctx_vec):
         """x2d [B*N, C] fp16 residual stream; ctx_vec [B, C] = attn2's constant (single_token_context)."""
         p = self.pk()
-        a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
         a1 = self.attn1.pk()
+        if self.linear_fp8:                      # BASELINE configs[4]: LayerNorm emits e4m3 + a scale per token; q|k, V^T and the GEGLU projection read it
+            a = self.attn1.self_attention_f8(*ops.layernorm_f8(x2d, p.g1, p.b1, p.eps1), B, N)
+            x1 = ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec, group_rows=N, resid=x2d)
+            return self.ff.run_f8(*ops.layernorm_f8(x1, p.g3, p.b3, p.eps3), resid=x1)
+        a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
         x1 = ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec, group_rows=N, resid=x2d)          # attn1 + x, + attn2 constant
         return self.ff.run(ops.layernorm(x1, p.g3, p.b3, p.eps3), resid=x1)
 

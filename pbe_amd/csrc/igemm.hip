@@ -38,6 +38,8 @@ struct IGemmP {
     // conv gather
     int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 64)
     int th;                                              // MODE 2: image rows per tile (tile = th full rows, or whole images)
+    // fp8 (OCP e4m3) operands: rows are bytes (the loader sees them as K/2 halfs); C = acc * sa[m] * sw[n] (* alpha) + ...
+    const float* sa; const float* sw; long ssa, ssw;
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
@@ -69,8 +71,21 @@ __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false>
+typedef long i64;
+// one 16-byte fragment = two 8-byte fp8 operands: both MFMAs take the SAME byte positions from the two matrices, so together
+// they contract the 64 k-values of a (4 lane-quads x 16 bytes) k-step whatever order the hardware assigns inside an operand
+__device__ __forceinline__ f32x4 mfma_pair_f8(const h16x8& w, const h16x8& a, f32x4 acc) {
+    typedef i64 i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 wv = __builtin_bit_cast(i64x2, w), av = __builtin_bit_cast(i64x2, a);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[0], av[0], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[1], av[1], acc, 0, 0, 0);
+}
+
+template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    // F8 (MODE 0 only): A and W hold OCP e4m3 bytes, a k-tile row of 128 B is 128 k-values; v_mfma_f32_16x16x32_fp8_fp8 runs at
+    // the fp16 MFMA's rate, the gain is half the bytes through the fill path that bounds these GEMMs.  The epilogue multiplies
+    // by the per-row scale of A and the per-row scale of W (per output column) before bias / activation / residual.
     // MODE 2 = 3x3 conv (stride 1, pad 1) with the activation HALO resident in LDS: a tile is BM pixels = whole image rows (or whole
     // images); for every 64-channel block its (rows + 2) x (width + 2) halo (HPA rows of 128 B, zero outside the image) is staged
     // ONCE and all 9 taps read their shifted windows from it, so only the weight tile streams per k-tile.  MODE 1 re-stages the
@@ -234,7 +249,16 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const int rsw = (fq ^ (fr & 7)) << 4;             // byte offset of k-step 0's chunk; k-step 1 is rsw ^ 64
     const int a_rd = (wm * WM + fr) * 128, w_rd = (wn * WN + fr) * 128;
 
+    float* sca = svec + 4 * BN;                       // F8: per-row scale of A for this tile's rows, then per-column scale (W's rows)
+    float* scw = sca + BM;
     auto stage_svec = [&]() {
+        if constexpr (F8) {
+            for (int idx = tid; idx < BM + BN; idx += NT) {
+                float v = 1.f;
+                if (idx < BM) { if (p.sa && m0 + idx < p.M) v = p.sa[bz * p.ssa + m0 + idx]; sca[idx] = v; }
+                else { const int c = idx - BM; if (p.sw && n0 + c < p.N) v = p.sw[bz * p.ssw + n0 + c]; scw[c] = v; }
+            }
+        }
         if (p.sv_ok && p.splits <= 1) {                  // staged AFTER the first DMAs are in flight: both latencies overlap
             const int s0 = p.rowvec ? m0 / p.group_rows : 0;
             for (int idx = tid; idx < sv_ns * BN; idx += NT) {
@@ -520,7 +544,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = F8 ? mfma_pair_f8(fw[0][i], fa[0][j], acc[i][j]) : __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
         if constexpr (!BOTH) {
 #pragma unroll
             for (int j = 0; j < TM; ++j) fa[0][j] = *reinterpret_cast<const h16x8*>(sa + a_rd + (rsw ^ 64) + j * 16 * 128);
@@ -531,7 +555,8 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = F8 ? mfma_pair_f8(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j])
+                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
         slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
@@ -598,8 +623,15 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             for (int j = 0; j < TM; ++j) {
                 const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
                 float v[4];
+                if constexpr (F8) {
+                    const float sm = sca[g * GR + ml] * al;
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(scw + nl);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, bn[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], bn[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, bn[r]);
+                }
                 if (!F) {
                     const int m = m0 + g * GR + ml;
                     if (p.sv_ok) {                           // several samples per tile (8x8 level), or a per-row bias
@@ -886,7 +918,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
 
 int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): ping-pong main loop of the halo-resident conv tiles
 
-template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false>
+template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // (ping-pong only where a wave's MFMA phase - (BM/NWM/16) x (BN/NWN/16) x 2 MFMAs - is as long as its read phase: measured
     //  25 % SLOWER on the 128x160 halo tile, whose 20 MFMAs cannot cover 14 fragment reads + 3 DMA issues)
@@ -895,23 +927,24 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     }
     constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 + 1024 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float);   // + svec[4][BN]
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float) +  // + svec[4][BN]
+                           (F8 ? (BM + BN) * sizeof(float) : 0);                                                                       // + operand scales
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;
     pbe_prof_begin(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     {   // algorithmic bytes: every operand once (fp16): activations, weights, output, fused residual
         const double nout = p.act == PBE_ACT_GEGLU ? p.N * 0.5 : (double)p.N;
         const double a_el = MODE != 0 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
         const double w_el = (double)p.N * p.K * ((MODE == 0 && p.sW) ? batch : 1);
         const double c_el = (double)p.M * nout * batch * (p.resid ? 2.0 : 1.0);
-        pbe_prof_end(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch, 2.0 * (a_el + w_el + c_el));
+        pbe_prof_end(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K * batch * (F8 ? 2.0 : 1.0), 2.0 * (a_el + w_el + c_el));
     }
     if (p.splits > 1) {
         const long work = (long)p.M * (p.N >> 2);
@@ -944,6 +977,21 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
         case 13: if constexpr (MODE == 1) launch_cfg<256, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
         case 14: if constexpr (MODE == 1) launch_cfg<128, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
         default: launch_cfg<64, 64, 2, 2, 2, MODE>(p, batch, s); break;
+    }
+}
+
+// fp8 operands: a subset of the dense tiles (no split-K: the slab reduce does not carry the operand scales)
+static void dispatch_igemm_f8(IGemmP p, int batch, hipStream_t s, int want_cfg) {
+    g_pbe_allow_splitk = 0;
+    const Plan pl = plan_igemm(p, batch, 0, want_cfg, 0);
+    g_pbe_allow_splitk = 1;
+    p.splits = 1;
+    switch (pl.cfg) {
+        case 3: case 0: case 1: case 2: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 4: launch_cfg<128, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 5: case 6: launch_cfg<64, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 8: case 7: launch_cfg<128, 320, 2, 4, 2, 0, 0, false, true>(p, batch, s); break;
+        default: launch_cfg<128, 160, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
     }
 }
 
@@ -983,6 +1031,17 @@ static int fill_gemm(const pbe_gemm_desc* d, IGemmP& p, const char* who) {
     p.vec = (Nout % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
     p.ws = (float*)d->workspace;
+    if (d->operand_dtype == PBE_DTYPE_F8E4M3) {
+        // A / W are bytes: [M, K] and [N, K] e4m3, leading dims and batch strides in BYTES.  The loader addresses halfs, so K, K1 and
+        // the operand strides are halved (K % 16 == 0 keeps every 16-byte chunk whole).
+        PBE_REQUIRE(!d->A2 && d->K % 16 == 0 && d->lda % 16 == 0 && d->ldw % 16 == 0 && d->strideA % 16 == 0 && d->strideW % 16 == 0,
+                    "%s: fp8 operands need K, lda, ldw and batch strides in multiples of 16 bytes and a single A source", who);
+        PBE_REQUIRE(d->a_scale && d->w_scale, "%s: fp8 operands need a_scale [M] and w_scale [N]", who);
+        p.K = d->K / 2; p.K1 = p.K; p.lda = d->lda / 2; p.ldw = d->ldw / 2; p.sA = d->strideA / 2; p.sW = d->strideW / 2;
+        p.sa = d->a_scale; p.sw = d->w_scale; p.ssa = d->a_scale_stride; p.ssw = d->w_scale_stride;
+    } else {
+        PBE_REQUIRE(d->operand_dtype == PBE_DTYPE_F16, "%s: unknown operand_dtype %d", who, d->operand_dtype);
+    }
     return PBE_OK;
 }
 
@@ -991,7 +1050,8 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     const int rc = fill_gemm(d, p, "pbe_gemm_f16");
     if (rc != PBE_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
+    if (d->operand_dtype == PBE_DTYPE_F8E4M3) dispatch_igemm_f8(p, d->batch, s, d->tile_cfg);
+    else dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     PBE_LAUNCH_CHECK("pbe_gemm_f16");
     return PBE_OK;
 }

@@ -325,6 +325,90 @@ extern "C" int pbe_layernorm_f16(const void* X, const float* gamma, const float*
     return PBE_OK;
 }
 
+// LayerNorm with an fp8 (OCP e4m3) output and one scale per row: y8[r, :] = e4m3(LN(x[r, :]) / s[r]), s[r] = max|LN(x[r, :])| / 448.
+// Feeds the fp8 form of pbe_gemm_f16 (a_scale = s): the normalised row never exists in fp16 in HBM (half the bytes of the
+// fp16 LayerNorm's write and of the GEMM's A read).  Same two-pass statistics as layernorm_kernel.
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_f8_kernel(const h16* X, const float* gamma, const float* beta, unsigned char* Y, float* S,
+                                                            long rows, int C, long ldx, long ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    float y[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            const h16x8 x = *reinterpret_cast<const h16x8*>(X + row * ldx + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { y[i][e] = (float)x[e]; sum += y[i][e]; }
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = y[i][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[i][e] = (y[i][e] - mean) * rstd * g0[e] + b0[e];
+                y[i][4 + e] = (y[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(y[i][e]));
+        }
+    }
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / scale;
+    if (lane == 0) S[row] = scale;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            unsigned int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][0] * inv, y[i][1] * inv, w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][2] * inv, y[i][3] * inv, w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][4] * inv, y[i][5] * inv, w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][6] * inv, y[i][7] * inv, w1, true);
+            *reinterpret_cast<uint2*>(Y + row * ldy + v * 8) = make_uint2(w0, w1);
+        }
+    }
+}
+
+extern "C" int pbe_layernorm_f8(const void* X, const float* gamma, const float* beta, void* Y, float* row_scale, int64_t rows, int32_t C,
+                                int64_t ldx, int64_t ldy, float eps, pbe_stream_t stream) {
+    PBE_REQUIRE(X && gamma && beta && Y && row_scale, "pbe_layernorm_f8: null operand");
+    PBE_REQUIRE(rows > 0 && C > 0 && C % 16 == 0 && C <= 2048, "pbe_layernorm_f8: C=%d must be a multiple of 16, <= 2048", C);
+    PBE_REQUIRE(ldx % 8 == 0 && ldy % 16 == 0 && ldx >= C && ldy >= C, "pbe_layernorm_f8: bad leading dims (ldy in bytes, multiple of 16)");
+    PBE_REQUIRE(((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0, "pbe_layernorm_f8: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    pbe_prof_begin(PBE_K_LNORM, s);
+    const int vpl = (C / 8 + 63) / 64;
+#define PBE_LN8(V) hipLaunchKernelGGL(layernorm_f8_kernel<V>, grid, block, 0, s, (const h16*)X, gamma, beta, (unsigned char*)Y, row_scale, (long)rows, C, (long)ldx, (long)ldy, eps)
+    if (vpl <= 1) PBE_LN8(1); else if (vpl == 2) PBE_LN8(2); else if (vpl == 3) PBE_LN8(3); else PBE_LN8(4);
+#undef PBE_LN8
+    pbe_prof_end(PBE_K_LNORM, s, 3.0 * (double)rows * C);
+    PBE_LAUNCH_CHECK("pbe_layernorm_f8");
+    return PBE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row softmax with a scale (VAE mid-block attention scores): one workgroup per row, three
 // sweeps over the row (max, sum, write); the 8-18 KB row stays in L2 between sweeps.

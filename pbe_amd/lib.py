@@ -8,7 +8,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBE_LIB_PATH") or os.path.join(_HERE, "libpbe_hip.so")     # PBE_LIB_PATH: diagnostic builds (tools/) only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -20,7 +20,8 @@ class GemmDesc(C.Structure):
                 ("ldv", c_i32), ("group_rows", c_i32),
                 ("strideA", c_i64), ("strideW", c_i64), ("strideC", c_i64), ("strideR", c_i64),
                 ("batch", c_i32), ("alpha", c_f32), ("act", c_i32), ("bias_per_row", c_i32),
-                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32)]
+                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32),
+                ("a_scale", c_vp), ("w_scale", c_vp), ("a_scale_stride", c_i64), ("w_scale_stride", c_i64), ("operand_dtype", c_i32)]
 
 
 class Conv3x3Desc(C.Structure):
@@ -50,6 +51,7 @@ SYMBOLS = {
     "pbe_groupnorm_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "pbe_groupnorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp, c_sz, c_vp]),
     "pbe_layernorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
+    "pbe_layernorm_f8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
     "pbe_attention_f16": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "pbe_softmax_rows_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
     "pbe_geglu_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),

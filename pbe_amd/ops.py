@@ -321,6 +321,70 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y.view(x.shape)
 
 
+def layernorm_f8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """LayerNorm with an fp8 (OCP e4m3) output: returns (y8 uint8 [rows, C], row_scale fp32 [rows]); y = y8 * row_scale[:, None]."""
+    _h(x, "layernorm_f8 x"); _f(gamma, "layernorm_f8 gamma"); _f(beta, "layernorm_f8 beta")
+    x2 = x.reshape(-1, x.shape[-1])
+    rows, Cc, ldx = _rows(x2, "layernorm_f8 x")
+    y = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    with _timed(f"l8:{rows}:{Cc}"):
+        _l.check(_l.load().pbe_layernorm_f8(_p(x2), _p(gamma), _p(beta), _p(y), _p(sc), rows, Cc, ldx, Cc, float(eps), _stream()), "pbe_layernorm_f8")
+    return y, sc
+
+
+def gemm_f8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+            resid: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, n] = act(alpha * a_scale[m] * w_scale[n] * sum_k a8[m, k] w8[n, k] + bias) + resid with OCP e4m3 operands (uint8
+    tensors) and fp16 output.  2-D operands, or 3-D [batch, rows, K] for a strided batch (w8 / w_scale may have batch 1)."""
+    _req(a8, torch.uint8, "gemm_f8 a8"); _req(w8, torch.uint8, "gemm_f8 w8"); _f(a_scale, "gemm_f8 a_scale"); _f(w_scale, "gemm_f8 w_scale")
+    batch = 1
+    sA = sW = sC = 0
+    ssa = ssw = 0
+    if a8.dim() == 3:
+        batch = a8.shape[0] if a8.stride(0) != 0 else max(a8.shape[0], w8.shape[0])
+        if a8.stride(2) != 1 or w8.dim() != 3 or w8.stride(2) != 1:
+            raise _l.PbeError("gemm_f8: bad batched operands")
+        M, K, lda, sA = a8.shape[1], a8.shape[2], a8.stride(1), a8.stride(0)
+        N, Kw, ldw, sW = w8.shape[1], w8.shape[2], w8.stride(1), w8.stride(0)
+        ssa = a_scale.stride(0) if a_scale.dim() == 2 else 0
+        ssw = w_scale.stride(0) if w_scale.dim() == 2 else 0
+        if out is None:
+            out = torch.empty((batch, M, N), dtype=torch.float16, device=a8.device)
+        ldc, sC = out.stride(1), out.stride(0)
+    else:
+        M, K, lda = _rows(a8, "gemm_f8 a8")
+        N, Kw, ldw = _rows(w8, "gemm_f8 w8")
+        if out is None:
+            out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), dtype=torch.float16, device=a8.device)
+        ldc = _rows(out, "gemm_f8 out")[2]
+    if Kw != K:
+        raise _l.PbeError(f"gemm_f8: K mismatch, activations {K} vs weights {Kw}")
+    if a_scale.numel() < M or w_scale.numel() < N:
+        raise _l.PbeError("gemm_f8: scale vectors too short")
+    ldr = 0
+    if resid is not None:
+        ldr = _rows(_h(resid, "gemm_f8 resid"), "gemm_f8 resid")[2]
+    if bias is not None:
+        _f(bias, "gemm_f8 bias")
+    d = _l.GemmDesc(_p(a8), None, _p(w8), _p(_h(out, "gemm_f8 out")), _p(bias), None, _p(resid), M, N, K, K, lda, 0, ldw, ldc, ldr,
+                    0, 0, sA, sW, sC, 0, batch, float(alpha), act, 0, None, 0, _tile_cfg(f"g8:{M}:{N}:{K}:{batch}"),
+                    _p(a_scale), _p(w_scale), ssa, ssw, 1)
+    with _timed(f"g8:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}"):
+        _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16 (fp8 operands)")
+    return out
+
+
+def pack_linear_f8(w: torch.Tensor):
+    """[N, K] fp32 weight -> (OCP e4m3 bytes uint8 [N, K], fp32 scale [N]) with one scale per output channel: w ~ w8 * scale[:, None].
+    One-off, at pack time (BASELINE configs[4])."""
+    w2 = w.detach().reshape(w.shape[0], -1).float()
+    amax = w2.abs().amax(1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    w8 = (w2 / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return w8, scale.contiguous()
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, Nq: int, Nk: int, D: int, scale: float, *,
               q_strides: Tuple[int, int], k_strides: Tuple[int, int], vt_strides: Tuple[int, int],
               out: Optional[torch.Tensor] = None) -> torch.Tensor:

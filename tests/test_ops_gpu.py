@@ -496,3 +496,68 @@ def test_resize_bilinear_against_torch(dev):
             assert err <= 2e-6, (tuple(x.shape), size, aa, err)
     binary = ops.resize_bilinear(mask.to(dev), (64, 64), True).cpu()
     assert -1e-6 <= binary.min() and binary.max() <= 1.0 + 1e-6 and ((binary > 1e-3) & (binary < 1 - 1e-3)).any()        # edges are NOT re-binarised
+
+
+# ---- fp8 (OCP e4m3) operand path: BASELINE configs[4] ----------------------------------------------------------------------
+def _deq(w8, scale):
+    return w8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("M,N,K,geglu,resid", [(192, 160, 128, False, False), (4096, 640, 320, False, True), (2048, 2560, 320, True, False),
+                                               (1000, 96, 1280, False, False), (256, 1280, 640, False, True), (64, 64, 16, False, False)])
+def test_gemm_f8_exact_against_dequantised_operands(dev, M, N, K, geglu, resid):
+    """The fp8 operand form of pbe_gemm_f16 computes EXACTLY the product of the dequantised operands (e4m3 x e4m3 products are exact
+    in fp32; only the fp32 accumulation order and the fp16 output rounding remain): compared with torch fp32 on a8 * sa, w8 * sw."""
+    from pbe_amd import ops
+    g = _g(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    a8, sa = ops.pack_linear_f8(a)                       # same quantiser for both operands in this test
+    w8, sw = ops.pack_linear_f8(w)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).half() if resid else None
+    ref = _deq(a8, sa) @ _deq(w8, sw).t() + bias
+    if geglu:
+        wi = torch.stack([w8[:N // 2], w8[N // 2:]], 1).reshape(N, K)
+        si = torch.stack([sw[:N // 2], sw[N // 2:]], 1).reshape(N)
+        bi = torch.stack([bias[:N // 2], bias[N // 2:]], 1).reshape(N)
+        got = ops.gemm_f8(a8.to(dev), sa.to(dev), wi.to(dev), si.to(dev), bi.to(dev), act=ops.ACT_GEGLU)
+        ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:])
+    else:
+        got = ops.gemm_f8(a8.to(dev), sa.to(dev), w8.to(dev), sw.to(dev), bias.to(dev), resid=None if res is None else res.to(dev))
+        if res is not None:
+            ref = ref.half().float() + res.float()
+    _close(got, ref, rtol=1.5e-3, atol=1.5e-3, what=f"gemm_f8 {M}x{N}x{K}")
+
+
+def test_gemm_f8_batched_vt_layout(dev):
+    """The V^T projection form: weights as the A operand (shared over the batch, scale per channel), activations as W (scale per token)."""
+    from pbe_amd import ops
+    g = _g(5)
+    B, N, Cc, inner = 3, 200, 320, 256
+    x = torch.randn(B, N, Cc, generator=g)
+    w = torch.randn(inner, Cc, generator=g) / math.sqrt(Cc)
+    x8, sx = ops.pack_linear_f8(x.reshape(B * N, Cc))
+    w8, sw = ops.pack_linear_f8(w)
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, inner, npad, dtype=torch.float16, device=dev)
+    ops.gemm_f8(w8.to(dev).unsqueeze(0).expand(B, -1, -1), sw.to(dev), x8.to(dev).view(B, N, Cc), sx.to(dev).view(B, N), out=vt[:, :, :N])
+    ref = torch.einsum("ik,bnk->bin", _deq(w8, sw), _deq(x8, sx).view(B, N, Cc))
+    _close(vt[:, :, :N], ref, rtol=1.5e-3, atol=1.5e-3, what="gemm_f8 V^T")
+
+
+def test_layernorm_f8(dev):
+    """pbe_layernorm_f8: y8 * scale reproduces LayerNorm within e4m3 rounding (relative 2^-4 per element), the row maximum maps to
+    +-448 exactly, and the bytes equal torch's own e4m3 rounding of LN(x) / scale."""
+    from pbe_amd import ops
+    g = _g(8)
+    for rows, Cc in ((300, 320), (64, 1280), (17, 640)):
+        x = (torch.randn(rows, Cc, generator=g) * 2 + 0.3).half()
+        gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+        y8, sc = ops.layernorm_f8(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
+        ref = F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5)
+        deq = y8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]
+        assert torch.allclose(sc.cpu(), ref.abs().amax(1) / 448.0, rtol=2e-3)
+        err = (deq - ref).abs()
+        assert (err <= ref.abs() * 2 ** -4 + sc.cpu()[:, None] * 2 ** -9 + 2e-3).all(), err.max()
+        assert (y8.cpu().view(torch.float8_e4m3fn).float().abs().amax(1) == 448.0).all()
