@@ -93,7 +93,7 @@ if __name__ == "__main__" and "RANK" not in os.environ:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_IMAGE = 85.08e12          # 51*2*796.94 + 1116.7 + 2514.5 + 155.5 + 0.13 GFLOP
+# algorithmic FLOP per image at the headline config = 85.08e12 (51*2*796.94 + 1116.7 + 2514.5 + 155.5 + 0.13 GFLOP); main() computes it
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_TBS = 8.0                 # HBM3E spec, same table (6.3 TB/s is what a streaming copy reaches)
 
