@@ -370,6 +370,7 @@ def gemm_f8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: 
     d = _l.GemmDesc(_p(a8), None, _p(w8), _p(_h(out, "gemm_f8 out")), _p(bias), None, _p(resid), M, N, K, K, lda, 0, ldw, ldc, ldr,
                     0, 0, sA, sW, sC, 0, batch, float(alpha), act, 0, None, 0, _tile_cfg(f"g8:{M}:{N}:{K}:{batch}"),
                     _p(a_scale), _p(w_scale), ssa, ssw, 1)
+    _launch_note(d, f"g8:{M}:{N}:{K}:{batch}", False)
     with _timed(f"g8:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}"):
         _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16 (fp8 operands)")
     return out

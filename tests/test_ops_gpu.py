@@ -200,6 +200,31 @@ def test_conv3x3_halo_tiles(dev, B, H, W, C1, C2, Co, cfg):
     assert torch.equal(outs[cfg], outs[9]), f"halo tile {cfg} and the gather kernel differ in {int((outs[cfg] != outs[9]).sum())} elements"
 
 
+def test_conv3x3_halo_pingpong_race_screen(dev):
+    """The ping-pong main loop of the large halo tiles is a hand-placed barrier / vmcnt schedule (hazards argued in igemm.hip): screen it
+    over repeated launches at three sizes - every launch must reproduce the gather kernel's bits (an early LDS read or a premature slot
+    refill would show as rare wrong tiles; cdna_hip_programming.md: "screen a new sync structure over many runs at several sizes")."""
+    from pbe_amd import ops
+    for (B, H, C1, Co, cfg) in ((8, 64, 320, 320, 10), (8, 32, 640, 640, 12), (8, 16, 1280, 640, 10)):
+        g = _g(H + C1 + cfg)
+        x = torch.randn(B, H, H, C1, generator=g).half().to(dev)
+        wp = ops.pack_conv3x3((torch.randn(Co, C1, 3, 3, generator=g) / math.sqrt(9 * C1))).to(dev)
+        b = torch.randn(Co, generator=g).to(dev)
+        noise = torch.randn(64 << 20, device=dev)            # a streaming kernel in between: uneven memory load on the CUs
+        try:
+            ops.tune(1, 9 | (1 << 8))
+            ref = ops.conv3x3(x, wp, b)
+            ops.tune(1, cfg | (1 << 8))
+            bad = 0
+            for i in range(60):
+                if i % 3 == 0:
+                    noise.mul_(1.0001)
+                bad += int(not torch.equal(ops.conv3x3(x, wp, b), ref))
+            assert bad == 0, f"{bad} of 60 launches of halo tile {cfg} at {H}x{H} differ from the gather kernel"
+        finally:
+            ops.tune(1, -1)
+
+
 def test_conv3x3_halo_split_k(dev):
     """Halo tiles split K at channel-block boundaries: 1280 -> 1280 at 8x8 (20 blocks) with factors 2 .. 7 against torch fp32."""
     from pbe_amd import ops

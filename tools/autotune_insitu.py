@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tuned_insitu.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "autotune_insitu_report.txt"))
     ap.add_argument("--merge", default="", help="start from this table; shapes measured here replace their entries")
+    ap.add_argument("--image-size", type=int, default=512, help="768 = BASELINE configs[4] geometry")
+    ap.add_argument("--precision", default="fp16", choices=("fp16", "fp8"))
     a = ap.parse_args()
     import cases
     import modelbuild
@@ -70,8 +72,11 @@ def main():
     t0 = time.time()
     with torch.no_grad():
         model = modelbuild.full_model(dev)
+        if a.precision == "fp8":
+            from pbe_amd.precision import set_linear_precision
+            set_linear_precision(model, "fp8")
         for B in [int(b) for b in a.batches.split(",")]:
-            inp = {k: v.to(dev) for k, v in cases.synthetic_triples(B, 512).items()}
+            inp = {k: v.to(dev) for k, v in cases.synthetic_triples(B, a.image_size).items()}
             one_pass(model, inp, a.steps, -1)                                   # warm: packs, workspaces
             cands = [cfg | (sp << 8) for cfg in range(NCFG) for sp in SPLITS]
             data = {}                                                            # key -> {(cfg, splits): [us, ...]}
