@@ -45,14 +45,15 @@ def main(fdir, wdir, outp):
     ft, fn = per_kernel(fdir, "FETCH_SIZE")
     wt, wn = per_kernel(wdir, "WRITE_SIZE")
 
-    def mode_of(k):                                   # igemm_kernel<BM, BN, NWM, NWN, MODE, S>: MODE 1 = 3x3 conv, 0 = dense GEMM
+    def mode_of(k):                                   # igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>: MODE 1 / 2 = 3x3 conv (gather / halo), 0 = dense GEMM
         if not k.startswith("igemm_kernel<"):
             return None
         args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
         return args[4] if len(args) >= 5 else None
     classes = {}
-    for cname, mode, label in (("conv3x3_igemm", "1", "igemm_kernel<*,*,*,*,1,*> (3x3 conv implicit GEMM)"), ("gemm", "0", "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)")):
-        ks = [k for k in ft if mode_of(k) == mode]
+    for cname, modes, label in (("conv3x3_igemm", ("1", "2"), "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)"),
+                                ("gemm", ("0",), "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)")):
+        ks = [k for k in ft if mode_of(k) in modes]
         launches = sum(fn[k] for k in ks)
         assert launches and launches == sum(wn[k] for k in ks), (cname, launches, sum(wn[k] for k in ks))
         rd = sum(ft[k] for k in ks) * 1024 * 2
