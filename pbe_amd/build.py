@@ -103,6 +103,11 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
 
 
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--diag="):                   # --diag=name:DEFINE[=v][,DEFINE...]  ->  tools/_dbg/libpbe_hip_<name>.so
+            name, defs = a[len("--diag="):].split(":", 1)
+            print(build_diagnostic(defs.split(","), os.path.join(HERE, "..", "tools", "_dbg", f"libpbe_hip_{name}.so")))
+            sys.exit(0)
     if "--stamps" in sys.argv:
         print(build_diagnostic(["PBE_STAMPS"], os.path.join(HERE, "..", "tools", "_dbg", "libpbe_hip_stamps.so")))
     else:

@@ -44,7 +44,7 @@ struct IGemmP {
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
 #ifdef PBE_STAMPS
-    unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 10 stamps per workgroup
+    unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 16 words per workgroup
 #endif
 };
 
@@ -55,11 +55,39 @@ struct IGemmP {
     do {                                                                                                               \
         if (p.stamps && threadIdx.x == 0) {                                                                            \
             const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                     \
-            p.stamps[wg_ * 10 + (i)] = (i) >= 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
+            p.stamps[wg_ * 16 + (i)] = (i) >= 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
+        }                                                                                                              \
+    } while (0)
+// main-loop accounting of wave 0: cycles inside the counted vmcnt waits (words 9), the barrier after the fragment reads (10) and
+// the barrier that ends a k-tile (11), DMA issue + fragment reads up to lgkmcnt(0) (12), the MFMA block (13)
+#define PBE_ACC_DECL unsigned long long acc_w_ = 0, acc_b1_ = 0, acc_b2_ = 0, acc_r_ = 0, acc_m_ = 0, acc_t_ = 0
+#define PBE_ACC_T0() acc_t_ = __builtin_amdgcn_s_memtime()
+#define PBE_ACC(v) v += __builtin_amdgcn_s_memtime() - acc_t_
+#define PBE_ACC_STORE()                                                                                                \
+    do {                                                                                                               \
+        if (p.stamps && threadIdx.x == 0) {                                                                            \
+            const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                     \
+            p.stamps[wg_ * 16 + 9] = acc_w_; p.stamps[wg_ * 16 + 10] = acc_b1_; p.stamps[wg_ * 16 + 11] = acc_b2_;    \
+            p.stamps[wg_ * 16 + 12] = acc_r_; p.stamps[wg_ * 16 + 13] = acc_m_;                                       \
         }                                                                                                              \
     } while (0)
 #else
 #define PBE_STAMP(i) do { } while (0)
+#define PBE_ACC_DECL do { } while (0)
+#define PBE_ACC_T0() do { } while (0)
+#define PBE_ACC(v) do { } while (0)
+#define PBE_ACC_STORE() do { } while (0)
+#endif
+
+// Priority of the MFMA block.  PBE_PRIO_MODE (diagnostic builds): 0 = per-block raise (the shipped form), 1 = none,
+// 2 = static: waves 4-7 of an 8-wave tile run at priority 1 for the whole main loop (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
+#ifndef PBE_PRIO_MODE
+#define PBE_PRIO_MODE 0
+#endif
+#if PBE_PRIO_MODE == 0
+#define PBE_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PBE_SETPRIO(x) do { } while (0)
 #endif
 
 __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 0u, 0u};
@@ -104,14 +132,19 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     constexpr int PA = BM / 8, PW = BN / 8;           // 8-row x 128-byte DMA pieces (1 KiB = one wave instruction)
     constexpr int LA = PA / NW, LW = (PW + NW - 1) / NW, LPT = LA + LW;
     constexpr int CLD = BN + 8;
-    // MODE 2 LDS: [halo image 0][halo image 1][weight ring S x BN rows][1 KiB dump for the padding DMAs]
-    constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES + 1024 : S * STAGE;
+    // MODE 2 LDS: [halo image 0][halo image 1][weight ring S x BN rows]
+    constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES : S * STAGE;
     static_assert(S >= 2 && S <= 4 && PA % NW == 0 && (PW % NW == 0 || MODE == 2) && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
     static_assert(MODE != 2 || (HPA % 8 == 0 && HPA >= BM), "halo image must hold the tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: every LDS-DMA destination below is an SGPR expression
     const int wm = wave % NWM, wn = wave / NWM;
+    PBE_ACC_DECL;
+#if PBE_PRIO_MODE == 2
+    if (NW == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     PBE_STAMP(0);                                    // workgroup start
     PBE_STAMP(7);                                    // wall clock (100 MHz) of the start
     int tile;
@@ -134,15 +167,19 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const int gch = (lane & 7) ^ lrow;
     const h16* zsrc = reinterpret_cast<const h16*>(g_pbe_zero16);
 
-    bool a_ok[LA];
-    const h16* a_row[LA];
-    const h16* a_row2[LA];
+    // A DMA piece must stay LEAN: tools/ubench_loop.hip (this loop's instruction mix, operands from L2) runs a k-tile of the
+    // 256x160 tile in 1 550-1 630 cycles with "pointer + scalar k offset" pieces and in 1 850-2 500 with the form this kernel used to
+    // compile to (per-lane zero-block select, LDS address through a VGPR, a branch per piece): next to MFMAs every VALU instruction
+    // of a piece waits for an issue slot.  So: rows beyond M / N are CLAMPED to the last row (their products land in accumulators
+    // that are never stored), the source pointer of a piece is one 64-bit add, its LDS address an SGPR; only a k-tile that needs
+    // per-lane zeros (K % 64 != 0: the last one) or straddles the two concatenated sources takes the select form.
+    const h16* a_cur[LA];                             // source row of each piece at k = 0, + this lane's chunk (current concat source)
+    const h16* a_alt[LA];                             // the same for the second source, pre-offset by -K1
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int m = m0 + (wave * LA + i) * 8 + lrow;
-        a_ok[i] = m < p.M;
-        a_row[i] = p.A + bz * p.sA + (long)m * p.lda;
-        a_row2[i] = p.A2 ? p.A2 + (long)m * p.lda2 : p.A;
+        const int m = min(m0 + (wave * LA + i) * 8 + lrow, p.M - 1);
+        a_cur[i] = p.A + bz * p.sA + (long)m * p.lda + gch * 8;
+        a_alt[i] = p.A2 ? p.A2 + (long)m * p.lda2 + gch * 8 - p.K1 : a_cur[i];
     }
     // conv: K is ordered (channel block cb, tap, channel) so the 9 taps of a pixel's cb channels are consecutive k-tiles -
     // the shifted re-reads hit L2 instead of going back to the Infinity Cache / HBM (measured: tap-major order re-fetched the
@@ -170,13 +207,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         }
         __syncthreads();
     }
-    bool w_ok[LW];
     const h16* w_row[LW];
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-        const int n = n0 + (wave + NW * i) * 8 + lrow;
-        w_ok[i] = n < p.N && wave + NW * i < PW;
-        w_row[i] = p.W + bz * p.sW + (long)(w_ok[i] ? n : 0) * p.ldw;
+        // (a padding piece - PW not a multiple of NW, halo tiles only - repeats the last real piece: same source, same LDS bytes)
+        const int n = min(n0 + min(wave + NW * i, PW - 1) * 8 + lrow, p.N - 1);
+        w_row[i] = p.W + bz * p.sW + (long)n * p.ldw + gch * 8;
     }
     const int nk_all = (p.K + 63) >> 6;
     int kt0 = 0, nk = nk_all;                        // this workgroup's k-tile range [kt0, nk)
@@ -192,22 +228,44 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         const int per_blk = 9 * KB, cblk = kt0 / per_blk, r = kt0 - cblk * per_blk;
         tap = r / KB; kj = r - tap * KB; c0 = cblk * p.cb + kj * 64;
     }
+    // MODE 1: per piece the running source pointer and its advance per k-tile (a padding pixel keeps reading the zero block: advance 0)
     const h16* a_src[LA];
+    int a_inc[LA];
     bool fresh = true;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) a_src[i] = zsrc;
+    for (int i = 0; i < LA; ++i) { a_src[i] = zsrc; a_inc[i] = 0; }
+    // MODE 0: the k-tile where the second concat source takes over, and the two rare k-tiles that need per-lane selects
+    const bool ktail = (p.K & 63) != 0, straddle = p.A2 && (p.K1 & 63);
+    const int kt_sw = p.A2 ? p.K1 >> 6 : 0x7fffffff;
+    if (MODE == 0 && kt0 > kt_sw) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a_cur[i] = a_alt[i];
+    }
 
-    auto issue = [&](int kt, int slot) {
+    auto issue = [&](int kt, int slot) {              // k-tiles are issued in order: kt0, kt0 + 1, ...
         unsigned char* sa = smem + slot * STAGE;
         unsigned char* sw = sa + A_BYTES;
-        const int k = kt * 64 + gch * 8;
-        const bool kok = k < p.K;
+        const long k = (long)kt * 64;                 // scalar
+        const bool slow = (ktail && kt == nk_all - 1) || (straddle && kt == kt_sw);      // uniform
+        const int kl = kt * 64 + gch * 8;             // this lane's k (slow form only)
         if (MODE == 0) {
+            if (kt == kt_sw && !straddle) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const h16* src = (k < p.K1) ? a_row[i] + k : a_row2[i] + (k - p.K1);
-                src = (a_ok[i] && kok) ? src : zsrc;
-                PBE_GLDS16(src, sa + (wave * LA + i) * 1024);
+                for (int i = 0; i < LA; ++i) a_cur[i] = a_alt[i];
+            }
+            if (!slow) {
+#pragma unroll
+                for (int i = 0; i < LA; ++i) PBE_GLDS16(a_cur[i] + k, sa + (wave * LA + i) * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    const h16* src = (kl < p.K1 ? a_cur[i] : a_alt[i]) + k;
+                    PBE_GLDS16(kl < p.K ? src : zsrc, sa + (wave * LA + i) * 1024);
+                }
+                if (straddle && kt == kt_sw) {
+#pragma unroll
+                    for (int i = 0; i < LA; ++i) a_cur[i] = a_alt[i];
+                }
             }
         } else {
             if (kj == 0 || fresh) {                   // new (block, tap): look the pixels up; otherwise +64 channels
@@ -218,13 +276,14 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
 #pragma unroll
                 for (int i = 0; i < LA; ++i) {
                     const int pix = tab[tap * BM + (wave * LA + i) * 8 + lrow];
-                    a_src[i] = pix >= 0 ? base + (long)pix * cs : nullptr;
+                    a_src[i] = pix >= 0 ? base + (long)pix * cs : zsrc;
+                    a_inc[i] = pix >= 0 ? 64 : 0;
                 }
             }
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                PBE_GLDS16(a_src[i] ? a_src[i] : zsrc, sa + (wave * LA + i) * 1024);
-                if (a_src[i]) a_src[i] += 64;
+                PBE_GLDS16(a_src[i], sa + (wave * LA + i) * 1024);
+                a_src[i] += a_inc[i];
             }
             c0 += 64;
             if (++kj == KB) {
@@ -232,10 +291,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 if (++tap == 9) tap = 0; else c0 -= p.cb;      // next tap of the same block, or first tap of the next block
             }
         }
+        if (!slow) {
 #pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            const h16* src = (w_ok[i] && kok) ? w_row[i] + k : zsrc;
-            PBE_GLDS16(src, sw + (wave + NW * i) * 1024);
+            for (int i = 0; i < LW; ++i) PBE_GLDS16(w_row[i] + k, sw + (wave + NW * i) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LW; ++i) PBE_GLDS16(kl < p.K ? w_row[i] + k : zsrc, sw + (wave + NW * i) * 1024);
         }
     };
 
@@ -280,8 +341,11 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         constexpr int PAH = HPA / 8, LAH = (PAH + NW - 1) / NW;
         unsigned char* abuf = smem;
         unsigned char* wring = smem + 2 * HPA * 128;
-        unsigned char* dump = wring + S * W_BYTES;
-        const int TW = p.Wd, TH = p.th, HW2 = TW + 2, HPS = (TH + 2) * HW2;      // halo rows of one image of the tile
+        // Halo image of one (sub-)image of the tile: TH + 2 rows of TW + 1 pixels + 1.  A tile spans the image's whole width, so
+        // x = -1 and x = TW are always padding: the zero row right of image row y IS the zero row left of image row y + 1
+        // (row stride TW + 1 instead of TW + 2; 4 rows of 64 pixels: 391 halo rows instead of 396 - what lets a third weight slot
+        // fit beside two halo images of a 256-pixel tile).
+        const int TW = p.Wd, TH = p.th, HW2 = TW + 1, HPS = (TH + 2) * HW2 + 1;
         const int img_px = TH * TW, nsub = BM / img_px;                             // nsub > 1: the tile holds nsub whole images
         const int tiles_per_img = p.H / TH;
         const int b0 = nsub > 1 ? tm_i * nsub : tm_i / tiles_per_img;
@@ -289,9 +353,9 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         int hpix[LAH];                                // source pixel of this lane's row in each of its halo pieces (-1: zero)
 #pragma unroll
         for (int i = 0; i < LAH; ++i) {
-            const int piece = wave + NW * i, hp = piece * 8 + lrow;
+            const int piece = min(wave + NW * i, PAH - 1), hp = piece * 8 + lrow;      // (padding pieces repeat the last real one)
             int pix = -1;
-            if (piece < PAH && hp < nsub * HPS) {
+            if (hp < nsub * HPS) {
                 const int sub = hp / HPS, r = hp - sub * HPS, hy = r / HW2, hx = r - hy * HW2;
                 const int y = y0 + hy - 1, x = hx - 1;
                 if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)TW) pix = ((b0 + sub) * p.H + y) * TW + x;
@@ -304,24 +368,34 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             const int ml = wm * WM + j * 16 + fr, sub = ml / img_px, rr = ml - sub * img_px, ty = rr / TW, tx = rr - ty * TW;
             hc[j] = sub * HPS + (ty + 1) * HW2 + tx + 1;
         }
-        auto issue_a = [&](int blk, int buf) {
+        // running source pointer of each halo piece (channel block by channel block, +64 channels; a padding row keeps reading the
+        // zero block) - rebuilt only where the channel blocks cross from the first concat source into the second
+        const h16* hptr[LAH];
+        auto halo_base = [&](int blk) {
             const int c0b = blk * 64;
             const bool first = c0b < p.C1;
             const h16* base = (first ? p.A + c0b : p.A2 + (c0b - p.C1)) + gch * 8;
             const long cs = first ? p.C1 : p.C2;
 #pragma unroll
             for (int i = 0; i < LAH; ++i) {
-                const int piece = wave + NW * i;
-                PBE_GLDS16(hpix[i] >= 0 ? base + (long)hpix[i] * cs : zsrc, piece < PAH ? abuf + buf * (HPA * 128) + piece * 1024 : dump);
+                hptr[i] = hpix[i] >= 0 ? base + (long)hpix[i] * cs : zsrc;
             }
         };
-        auto issue_w = [&](int kt, int slot) {
-            const int k = kt * 64 + gch * 8;
+        auto issue_a1 = [&](int buf_off, int i) {         // piece i (compile-time) of the next block in line, into the halo buffer at buf_off
+            PBE_GLDS16(hptr[i], abuf + buf_off + min(wave + NW * i, PAH - 1) * 1024);
+            hptr[i] += hpix[i] >= 0 ? 64 : 0;
+        };
+        auto issue_a = [&](int blk, int buf) {
+            if (p.C2 && blk * 64 == p.C1) halo_base(blk);
 #pragma unroll
-            for (int i = 0; i < LW; ++i) {
-                const int piece = wave + NW * i;
-                PBE_GLDS16(w_ok[i] ? w_row[i] + k : zsrc, (PW % NW == 0 || piece < PW) ? wring + slot * W_BYTES + piece * 1024 : dump);
-            }
+            for (int i = 0; i < LAH; ++i) issue_a1(buf * (HPA * 128), i);
+        };
+        auto issue_w1 = [&](int kt, int slot, int i) {
+            PBE_GLDS16(w_row[i] + (long)kt * 64, wring + slot * W_BYTES + min(wave + NW * i, PW - 1) * 1024);
+        };
+        auto issue_w = [&](int kt, int slot) {
+#pragma unroll
+            for (int i = 0; i < LW; ++i) issue_w1(kt, slot, i);
         };
         const int nblk_all = (p.C1 + p.C2) >> 6;
         int blk0 = 0, blk1 = nblk_all;                // this workgroup's channel blocks (split-K at block granularity)
@@ -333,127 +407,181 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         const int nk2 = blk1 * 9;
         PBE_STAMP(1);
         if (blk0 < blk1) {
+            halo_base(blk0);
             issue_a(blk0, 0);
 #pragma unroll
-            for (int t = 0; t < D; ++t) issue_w(blk0 * 9 + t, t);
+            for (int t = 0; t < (PP ? 2 : D); ++t) issue_w(blk0 * 9 + t, t);
         }
         PBE_STAMP(2);
         stage_svec();
         if constexpr (PP) {
-            // Ping-pong form (8 waves, two per SIMD).  With the halo resident a k-tile costs each wave 18 fragment reads, 2-3 weight
-            // DMAs and 40 MFMAs; in the plain loop both waves of a SIMD pass the barrier together, read LDS together (the LDS is
-            // the bottleneck for ~580 cycles) and then share the matrix pipe: 2 430 cycles per k-tile against 1 280 of MFMA work
-            // (profiles/r02_phase_stamps_halo_tiles.txt).  Here waves 0-3 and 4-7 alternate: in every half period one group
-            // reads its fragments while the other group's MFMAs own the pipe.
-            //   period i (tile kt), barriers b(2i-1) | b(2i) | b(2i+1):
-            //     start:        every wave issues W(kt + D) (and the next block's halo at tap 0)
-            //     first half:   group 0 reads tile kt's fragments      | group 1 runs the MFMAs of tile kt-1
-            //     second half:  group 0 runs the MFMAs of tile kt      | group 1 reads tile kt's fragments
-            //     end:          every wave retires ITS DMAs of tile kt+1 (counted vmcnt), lgkmcnt(0)
-            //   RAW: tile kt+1 is first read after b(2i+1), one barrier after every wave's wait.  WAR: the slot W(kt+1+D) lands in
-            //   (tile kt's) and the halo buffer of block blk-1 were last read before b(2i+1) / b(2i-1) (lgkmcnt(0) precedes both).
-            static_assert(NW == 8 && BOTH, "ping-pong needs two waves per SIMD and both k-steps' fragments in registers");
+            // Ping-pong form (8 waves, two per SIMD; weight ring of 3).  Waves 0-3 and 4-7 alternate: in every half period one group
+            // reads its 18 fragments of a k-tile while the other group's MFMAs own the matrix pipe.
+            //   period P (tile P), barriers b(2P-1) | b(2P) | b(2P+1):
+            //     first half:   group 0 reads tile P's fragments        | group 1 runs the MFMAs of tile P-1
+            //     second half:  group 0 runs the MFMAs of tile P        | group 1 reads tile P's fragments
+            //   Every wave issues its DMA pieces of period P - W(P + 2) and, at taps 0 .. LAH-1 of a block with a successor, ONE
+            //   piece of the next block's halo - right behind the fragment reads of its read half, and ends the period by retiring
+            //   what it issued before period P except period P-1's halo piece (counted vmcnt).  The first form of this loop (weight ring of 2, all 7 halo
+            //   pieces at tap 0, pieces with per-lane selects at the HEAD of the read half) spent 1 150 cycles in the read half
+            //   against 680 of MFMAs (tools/phase_stamps.py); spreading the pieces between the MFMAs was worse still.
+            //   RAW: tile P+1 (issued in period P-1) and a halo completed in period 9b+7 have landed for every wave at b(2P+1),
+            //   before their first read.  WAR: W(P+2) lands in tile P-1's slot and block b+1's halo in block b-1's buffer; their
+            //   last reads (group 1, second half of period P-1 / 9b-1) precede b(2P-1).
+            static_assert(NW == 8 && BOTH && S == 3 && LAH <= 8, "ping-pong: two waves per SIMD, both k-steps' fragments in registers, weight ring of 3");
             const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
             h16x8 fa[2][TM], fw[2][TN];
-            auto read_frags = [&](const unsigned char* ab, const unsigned char* sw, int tap) {
+            // The read half is the long pole (its partner group is computing: every VALU instruction here waits for an issue slot
+            // next to the partner's MFMAs - 930 cycles with the fragment addresses computed in place against 680 of MFMAs), so it
+            // holds NOTHING but the 18 ds_read_b128 and the DMA pieces: the LDS byte addresses of the next tile's fragments (tap
+            // shift, swizzle, halo buffer, ring slot) and the bumped weight pointers are computed inside the wave's OWN MFMA block,
+            // a few VALU instructions after every other MFMA, where the matrix pipe covers them.
+            int aaddr[2][TM], waddr[2];
+            auto tile_shift = [&](int tap) {
                 const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
-                const int shift = (trow - 1) * HW2 + (tap - 3 * trow - 1);
+                return (trow - 1) * HW2 + (tap - 3 * trow - 1);
+            };
+            auto frag_addrs = [&](int blk_n, int tap_n, int slot_n) {      // in one go (prologue only)
+                const int shift = tile_shift(tap_n), abase = ((blk_n - blk0) & 1) * (HPA * 128), wb = 2 * HPA * 128 + slot_n * W_BYTES;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int ar = hc[j] + shift;
+                    aaddr[0][j] = abase + ar * 128 + ((fq ^ (ar & 7)) << 4);
+                    aaddr[1][j] = aaddr[0][j] ^ 64;
+                }
+                waddr[0] = wb + w_rd + rsw;
+                waddr[1] = wb + w_rd + (rsw ^ 64);
+            };
+            auto read_frags = [&]() {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) {
-                        const int ar = hc[j] + shift;
-                        fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + ar * 128 + (((ks * 4 + fq) ^ (ar & 7)) << 4));
-                    }
+                    for (int j = 0; j < TM; ++j) fa[ks][j] = *reinterpret_cast<const h16x8*>(smem + aaddr[ks][j]);
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
+                    for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(smem + waddr[ks] + i * 16 * 128);
                 }
             };
-            auto mfmas = [&]() {
-                __builtin_amdgcn_s_setprio(1);
+            const int kt_first = blk0 * 9;
+            const h16* wp[LW];                             // weight pointers of the NEXT tile to issue
+            // One MFMA block = the wave's 2 TM TN MFMAs + (a few VALU instructions after every other one) the LDS byte addresses of
+            // the fragments of the tile this wave reads NEXT and the bumped weight pointers.
+            auto mfmas = [&](int shift_n, int abase_n, int wb_n) {
+                static_assert(TM * TN >= 2 * TM + 1 + LW, "not enough MFMAs to spread the address steps over");
+                PBE_SETPRIO(1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < TN; ++i)
 #pragma unroll
-                        for (int j = 0; j < TM; ++j)
+                        for (int j = 0; j < TM; ++j) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                            const int q = (ks * TN + i) * TM + j;             // compile-time after unrolling
+                            if (q & 1) {
+                                const int st = q >> 1;
+                                __builtin_amdgcn_sched_barrier(0);       // (each step pinned between its MFMAs: left free, the unrolled taps' steps
+                                if (st < 2 * TM) {                       //  are hoisted together and the block spills)
+                                    const int jj = st >> 1;
+                                    if ((st & 1) == 0) {
+                                        const int ar = hc[jj] + shift_n;
+                                        aaddr[0][jj] = abase_n + ar * 128 + ((fq ^ (ar & 7)) << 4);
+                                    } else aaddr[1][jj] = aaddr[0][jj] ^ 64;
+                                } else if (st == 2 * TM) { waddr[0] = wb_n + w_rd + rsw; waddr[1] = wb_n + w_rd + (rsw ^ 64); }
+                                else if (st < 2 * TM + 1 + LW) wp[st - 2 * TM - 1] += 64;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                PBE_SETPRIO(0);
             };
-            // One R block and one M block in the code (three inlined copies of the MFMA block spilled 270 B per thread):
-            // both groups run  R(kt) | barrier | M(kt) | barrier,  group 1 one barrier late; what differs per group is only WHERE
-            // in that sequence a period's DMA issue and wait sit (period start = group 0's R start = group 1's M start).
-            if (blk0 < blk1) {
-                if (D >= 2) wait_vmcnt<(D - 1) * LW>(); else wait_vmcnt<0>();      // halo of block blk0 and W(kt0) landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const int kt_first = blk0 * 9;
-                // the DMAs of the period whose tile is kt: W(kt + D) and, when kt opens a block, the next block's halo
-                auto issue_period = [&](int kt) {
-                    if (kt >= nk2) return;
-                    const int b = kt / 9, tp = kt - b * 9, i = kt - kt_first;
-                    if (kt + D < nk2) issue_w(kt + D, (i + D) % S);
-                    if (tp == 0 && b + 1 < blk1) issue_a(b + 1, (b + 1 - blk0) & 1);
-                };
-                // retire my DMAs of tile kt+1 at the end of period kt: later W tiles (kt+2 .. kt+D) and, at taps 0 .. D-1, the next
-                // block's halo pieces (issued after W(kt+1)) may stay in flight
-                auto wait_period = [&](int kt, int tap, bool next_a) {
-                    const int wleft = min(max(nk2 - 2 - kt, 0), D - 1);
-                    const bool a_young = next_a && tap <= D - 1;
-                    if (a_young) {
-                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
-                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
-                        else wait_vmcnt<LAH>();
-                    } else {
-                        if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW>();
-                        else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
-                        else wait_vmcnt<0>();
-                    }
-                };
-                if (grp == 1) {                            // the stagger: group 1 spends period 0's first half issuing only
-                    issue_period(kt_first);
-                    __builtin_amdgcn_s_barrier();
-                }
-                int slot_rd = 0, blk = blk0, tap = 0;
-                for (int kt = kt_first; kt < nk2; ++kt) {
+            // One channel block = 9 periods, UNROLLED: the tap, the ring slot (9 % 3 == 0: a block starts at slot 0), which DMA pieces
+            // a period issues and how many may stay in flight at its end are compile-time constants - the run-time form of this
+            // loop spent ~25 scalar branches per period on them (and copied the halo pointer arrays around a switch).
+            //   period (blk, tap) issues, right behind its fragment reads: W(kt + 2) into tile kt - 1's slot (unless the block is the
+            //   workgroup's last and tap >= 7) and piece `tap` of block blk + 1's halo (tap < LAH, unless last).
+            //   Its end retires everything issued before it EXCEPT the previous period's halo piece: the weight pieces of a period go
+            //   out before its halo piece and vmcnt retires in order, so that piece (activations no other workgroup shares: full
+            //   HBM / Infinity Cache latency) gets two periods to land.  At tap 8 neither this period nor the last issued one, so a
+            //   block's whole halo has landed before its first read.
+            auto block = [&](auto LASTC, int blk) {
+                constexpr bool LAST = decltype(LASTC)::value;
+                const int abase = ((blk - blk0) & 1) * (HPA * 128), abase_o = (HPA * 128) - abase;
+                if (!LAST && p.C2 && (blk + 1) * 64 == p.C1) halo_base(blk + 1);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
 #ifdef PBE_STAMPS
-                    if (kt == kt_first + 1) PBE_STAMP(3);
+                    if (tap == 1 && blk == blk0) PBE_STAMP(3);
 #endif
-                    const bool next_a = blk + 1 < blk1;
-                    if (grp == 0) issue_period(kt);
+                    constexpr int kLW = LW, kLAH = LAH;
+                    const bool w = !LAST || tap < 7, a = !LAST && tap < kLAH, a_prev = !LAST && tap >= 1 && tap - 1 < kLAH;
+                    auto wait_end = [&]() {
+                        if (w) { if (a && a_prev) wait_vmcnt<kLW + 2>(); else if (a || a_prev) wait_vmcnt<kLW + 1>(); else wait_vmcnt<kLW>(); }
+                        else { if (a && a_prev) wait_vmcnt<2>(); else if (a || a_prev) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+                    };
+                    PBE_ACC_T0();
                     __builtin_amdgcn_sched_barrier(0);
-                    read_frags(abuf + ((blk - blk0) & 1) * (HPA * 128), wring + slot_rd * W_BYTES, tap);
-                    if (grp == 1) wait_period(kt, tap, next_a);
+                    read_frags();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (w) {
+#pragma unroll
+                        for (int i = 0; i < LW; ++i) PBE_GLDS16(wp[i], wring + ((tap + 2) % 3) * W_BYTES + min(wave + NW * i, PW - 1) * 1024);
+                    }
+                    if (a) issue_a1(abase_o, tap);
+                    if (grp == 1) wait_end();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
+                    PBE_ACC(acc_r_);
+                    PBE_ACC_T0();
                     __builtin_amdgcn_s_barrier();
-                    if (grp == 1) issue_period(kt + 1);
+                    PBE_ACC(acc_b1_);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfmas();
-                    if (grp == 0) wait_period(kt, tap, next_a);
+                    PBE_ACC_T0();
+                    {   // this wave reads tile kt + 1 next: tap + 1 of this block, or tap 0 of the next (other halo buffer)
+                        const int tn = tap == 8 ? 0 : tap + 1, trow = tn / 3;
+                        // (the row stride re-materialised opaquely per tap: as a loop invariant, all 9 taps' fragment addresses are
+                        //  hoisted out of the block loop into 70 more registers and the kernel spills)
+                        int hw2 = HW2;
+                        asm volatile("" : "+s"(hw2));
+                        mfmas((trow - 1) * hw2 + (tn - 3 * trow - 1), tap == 8 ? abase_o : abase, 2 * HPA * 128 + ((tap + 1) % 3) * W_BYTES);
+                    }
+                    PBE_ACC(acc_m_);
+                    PBE_ACC_T0();
+                    if (grp == 0) wait_end();
+                    PBE_ACC(acc_w_);
                     __builtin_amdgcn_sched_barrier(0);
+                    PBE_ACC_T0();
                     __builtin_amdgcn_s_barrier();
-                    slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
-                    if (++tap == 9) { tap = 0; ++blk; }
+                    PBE_ACC(acc_b2_);
                 }
+            };
+            if (blk0 < blk1) {
+#pragma unroll
+                for (int i = 0; i < LW; ++i) wp[i] = w_row[i] + (long)(kt_first + 2) * 64;
+                frag_addrs(blk0, 0, 0);
+                wait_vmcnt<LW>();                           // halo of block blk0 and W(kt_first) landed; W(kt_first + 1) may be in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier late
+#pragma unroll 1
+                for (int blk = blk0; blk + 1 < blk1; ++blk) block(std::false_type{}, blk);
+                block(std::true_type{}, blk1 - 1);
                 if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last M phase
             }
         } else {
-        int slot_rd = 0, slot_wr = D % S;
+            int slot_rd = 0, slot_wr = D % S;
             for (int blk = blk0; blk < blk1; ++blk) {
                 const unsigned char* ab = abuf + ((blk - blk0) & 1) * (HPA * 128);
                 const bool next_a = blk + 1 < blk1;
-    #pragma unroll 1
+#pragma unroll 1
                 for (int tap = 0; tap < 9; ++tap) {          // (not unrolled: 9 copies of the body cost registers and 30 000 lines of ISA)
                     const int kt = blk * 9 + tap;
-    #ifdef PBE_STAMPS
+#ifdef PBE_STAMPS
                     if (kt == blk0 * 9 + 1) PBE_STAMP(3);
-    #endif
+#endif
                     // W(kt) must have landed.  Younger DMAs that may stay in flight: the later W tiles (D - 1, fewer at the end) and,
                     // at taps 1 .. D, the halo pieces of block blk + 1 (issued at tap 0 right after W(kt0 + D)).  The halo of THIS
                     // block is older than W(kt) (in-order vmcnt), so it has landed too.
                     const int wleft = min(nk2 - 1 - kt, D - 1);
                     const bool a_young = next_a && tap >= 1 && tap <= D;
+                    PBE_ACC_T0();
                     if (a_young) {
                         if (D >= 3 && wleft >= 2) wait_vmcnt<2 * LW + LAH>();
                         else if (D >= 2 && wleft >= 1) wait_vmcnt<LW + LAH>();
@@ -463,51 +591,54 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                         else if (D >= 2 && wleft >= 1) wait_vmcnt<LW>();
                         else wait_vmcnt<0>();
                     }
+                    PBE_ACC(acc_w_);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PBE_ACC_T0();
                     __builtin_amdgcn_s_barrier();
+                    PBE_ACC(acc_b2_);
                     const unsigned char* sw = wring + slot_rd * W_BYTES;
                     const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
                     const int shift = (trow - 1) * HW2 + (tap - 3 * trow - 1);
                     h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
                     int arow[TM];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < TM; ++j) arow[j] = hc[j] + shift;
-    #pragma unroll
+#pragma unroll
                     for (int ks = 0; ks < (BOTH ? 2 : 1); ++ks) {
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TM; ++j)
                             fa[ks][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((ks * 4 + fq) ^ (arow[j] & 7)) << 4));
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (kt + D < nk2) issue_w(kt + D, slot_wr);
                     if (tap == 0 && next_a) issue_a(blk + 1, (blk + 1 - blk0) & 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
+                    PBE_SETPRIO(1);
+#pragma unroll
                     for (int i = 0; i < TN; ++i)
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TM; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][i], fa[0][j], acc[i][j], 0, 0, 0);
                     if constexpr (!BOTH) {
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TM; ++j)
                             fa[0][j] = *reinterpret_cast<const h16x8*>(ab + arow[j] * 128 + (((4 + fq) ^ (arow[j] & 7)) << 4));
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ 64) + i * 16 * 128);
                     }
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < TN; ++i)
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TM; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
+                    PBE_SETPRIO(0);
                     slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
                     slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
                 }
             }
-}
+        }
     } else {
     PBE_STAMP(1);                                    // loader state (+ tap table) ready
 #pragma unroll
@@ -521,11 +652,16 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         if (kt == kt0 + 1) PBE_STAMP(3);             // first k-tile consumed: prologue latency ends
 #endif
         const int rem = min(nk - 1 - kt, D - 1);     // later tiles that may stay in flight
+        PBE_ACC_T0();
         if (D >= 3 && rem >= 2) wait_vmcnt<2 * LPT>();
         else if (D >= 2 && rem >= 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
+        PBE_ACC(acc_w_);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PBE_ACC_T0();
         __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot_wr (tile kt-1's) is free
+        PBE_ACC(acc_b2_);
+        PBE_ACC_T0();
         const unsigned char* sa = smem + slot_rd * STAGE;
         const unsigned char* sw = sa + A_BYTES;
         h16x8 fa[BOTH ? 2 : 1][TM], fw[BOTH ? 2 : 1][TN];
@@ -536,10 +672,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
 #pragma unroll
             for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const h16x8*>(sw + w_rd + (rsw ^ (ks * 64)) + i * 16 * 128);
         }
-        __builtin_amdgcn_sched_barrier(0);           // fragment reads go out first; the DMA address math runs in their shadow
-        if (kt + D < nk) issue(kt + D, slot_wr);
+        __builtin_amdgcn_sched_barrier(0);           // fragment reads go out first, the DMA pieces behind them (tools/ubench_loop.hip:
+        if (kt + D < nk) issue(kt + D, slot_wr);     //  cheaper there than before the reads, between the MFMAs or after them)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        PBE_ACC(acc_r_);
+        PBE_ACC_T0();
+        PBE_SETPRIO(1);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -557,13 +695,15 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             for (int j = 0; j < TM; ++j)
                 acc[i][j] = F8 ? mfma_pair_f8(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j])
                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[BOTH ? 1 : 0][i], fa[BOTH ? 1 : 0][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        PBE_SETPRIO(0);
+        PBE_ACC(acc_m_);
         slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
         slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PBE_STAMP(4);                                    // main loop issued
+    PBE_ACC_STORE();
 
     if (p.splits > 1) {
         // raw fp32 partial sums -> slab blockIdx.z; splitk_reduce_kernel applies the epilogue
@@ -623,27 +763,33 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             for (int j = 0; j < TM; ++j) {
                 const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
                 float v[4];
-                if constexpr (F8) {
-                    const float sm = sca[g * GR + ml] * al;
-                    const f32x4 sn = *reinterpret_cast<const f32x4*>(scw + nl);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], bn[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, bn[r]);
-                }
+                // every path forms  acc * alpha + (bias + row vector)  with the SAME association (the vector sum first, one fused
+                // multiply-add): which path a tile takes depends on the tile shape, and the tile shape must not change the bits
+                float add[4] = {bn[0], bn[1], bn[2], bn[3]};
                 if (!F) {
                     const int m = m0 + g * GR + ml;
                     if (p.sv_ok) {                           // several samples per tile (8x8 level), or a per-row bias
                         const f32x4 t = *reinterpret_cast<const f32x4*>(svec + (sv_ns > 1 ? (g * GR + ml) / p.group_rows : 0) * BN + nl);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += t[r];
+                        for (int r = 0; r < 4; ++r) add[r] = t[r];
                     } else if (p.rowvec && m < p.M) {
                         const h16* rv = p.rowvec + (long)(m / p.group_rows) * p.ldv + n;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (n + r < p.N) v[r] += (float)rv[r];
+                            if (n + r < p.N) add[r] = bn[r] + (float)rv[r];
                     }
+                }
+                if constexpr (F8) {
+                    const float sm = sca[g * GR + ml] * al;
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(scw + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], add[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, add[r]);
+                }
+                if (!F) {
+                    const int m = m0 + g * GR + ml;
                     if (p.bias && p.bias_row) {
                         const float bm = (m < p.M) ? p.bias[m] : 0.f;
 #pragma unroll
@@ -818,11 +964,17 @@ static const TileCfg kCfg[] = {
     {128, 320, 2, 4, 1, 0.96},           // 8: S = 2, 112 KiB: same, half the rows: fills the chip when M / 256 < 256 tiles
     {128, 160, 2, 2, 2, 0.90},           // 9: S = 2,  72 KiB, 4 waves: two workgroups per CU overlap each other's prologue / epilogue
     // halo-resident 3x3 conv tiles (stride 1, pad 1, image width 8 .. 128 = tile width): only the weights stream per k-tile
-    {256, 160, 4, 2, 1, 1.40, 400},      // 10: weight ring 2, 143 KiB: 256 pixels (4 rows at 64x64) x 160 channels, 8 waves
-    {128, 160, 4, 2, 1, 1.20, 264},      // 11: weight ring 3, 129 KiB: 128 pixels x 160 channels
-    {128, 320, 2, 4, 1, 1.25, 264},      // 12: weight ring 2, 150 KiB: 128 pixels x 320 channels
-    {256, 128, 4, 2, 1, 1.30, 400},      // 13: weight ring 3, 152 KiB: channel counts that are multiples of 128 only
-    {128, 128, 4, 2, 1, 1.10, 400}};     // 14: weight ring 3, 152 KiB: one 128-pixel row of a 128-wide image (VAE)
+    {256, 160, 4, 2, 1, 1.40, 392},      // 10: weight ring 3, 160 KiB: 256 pixels (4 rows at 64x64) x 160 channels, 8 waves, ping-pong
+    {128, 160, 4, 2, 1, 1.20, 264},      // 11: weight ring 3, 128 KiB: 128 pixels x 160 channels
+    {128, 320, 2, 4, 1, 1.25, 264},      // 12: weight ring 2, 149 KiB: 128 pixels x 320 channels
+    {256, 128, 4, 2, 1, 1.30, 392},      // 13: weight ring 3, 148 KiB: channel counts that are multiples of 128 only, ping-pong
+    {128, 128, 4, 2, 1, 1.10, 392},      // 14: weight ring 3, 148 KiB: one 128-pixel row of a 128-wide image (VAE)
+    // deep-ring forms of the small dense tiles, ONE workgroup per CU: for grids of <= 256 workgroups (M <= 2 048 rows) the second
+    // workgroup of a CU never arrives, and S = 2 then leaves one k-tile in flight per CU - a k-tile per DMA round trip
+    {128, 128, 2, 2, 1, 0.50},           // 15: S = 4, 128 KiB
+    {128, 64, 2, 2, 1, 0.40},            // 16: S = 4,  96 KiB
+    {64, 64, 2, 2, 2, 0.38},             // 17: S = 4,  64 KiB
+    {128, 160, 2, 2, 1, 0.52}};          // 18: S = 4, 144 KiB
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 #ifdef PBE_STAMPS
@@ -857,7 +1009,7 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
-static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1};
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1, 0.5, 0.4, 0.38, 0.52};
 
 // Can this conv run as a halo-resident tile of bm pixels with a halo image of hpa rows?  Returns the image rows per tile (0: no).
 static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
@@ -868,7 +1020,7 @@ static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
     if (H % th) return 0;
     const int nsub = bm / (th * W);                               // whole images per tile when the image is smaller than the tile
     if (nsub > 1 && th != H) return 0;
-    if (nsub * (th + 2) * (W + 2) > hpa) return 0;
+    if (nsub * ((th + 2) * (W + 1) + 1) > hpa) return 0;       // halo rows: row stride W + 1 (shared zero column) + 1
     return th;
 }
 
@@ -922,14 +1074,15 @@ template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool P
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // (ping-pong only where a wave's MFMA phase - (BM/NWM/16) x (BN/NWN/16) x 2 MFMAs - is as long as its read phase: measured
     //  25 % SLOWER on the 128x160 halo tile, whose 20 MFMAs cannot cover 14 fragment reads + 3 DMA issues)
-    if constexpr (MODE == 2 && !PP && (BM / NWM / 16) * (BN / NWN / 16) >= 16) {
+    if constexpr (MODE == 2 && !PP && S == 3 && (BM / NWM / 16) * (BN / NWN / 16) >= 16) {
         if (g_pbe_pingpong) { launch_cfg<BM, BN, NWM, NWN, S, MODE, HPA, true>(p, batch, s); return; }
     }
-    constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 + 1024 : (size_t)S * (BM + BN) * 128;
+    constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + 4 * BN * sizeof(float) +  // + svec[4][BN]
+    constexpr int SVR = (ring > c_bytes ? ring : c_bytes) + 4 * BN * sizeof(float) <= 160 * 1024 ? 4 : 3;                              // svec rows (samples per tile)
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + SVR * BN * sizeof(float) +     // + svec[SVR][BN]
                            (F8 ? (BM + BN) * sizeof(float) : 0);                                                                       // + operand scales
-    p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= 4);
+    p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= SVR);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
     pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), (int)lds);
@@ -971,11 +1124,15 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
         case 7: launch_cfg<256, 320, 2, 4, 2, MODE>(p, batch, s); break;
         case 8: launch_cfg<128, 320, 2, 4, 2, MODE>(p, batch, s); break;
         case 9: launch_cfg<128, 160, 2, 2, 2, MODE>(p, batch, s); break;
-        case 10: if constexpr (MODE == 1) launch_cfg<256, 160, 4, 2, 2, 2, 400>(p, batch, s); break;
+        case 10: if constexpr (MODE == 1) launch_cfg<256, 160, 4, 2, 3, 2, 392>(p, batch, s); break;
         case 11: if constexpr (MODE == 1) launch_cfg<128, 160, 4, 2, 3, 2, 264>(p, batch, s); break;
         case 12: if constexpr (MODE == 1) launch_cfg<128, 320, 2, 4, 2, 2, 264>(p, batch, s); break;
-        case 13: if constexpr (MODE == 1) launch_cfg<256, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
-        case 14: if constexpr (MODE == 1) launch_cfg<128, 128, 4, 2, 3, 2, 400>(p, batch, s); break;
+        case 13: if constexpr (MODE == 1) launch_cfg<256, 128, 4, 2, 3, 2, 392>(p, batch, s); break;
+        case 14: if constexpr (MODE == 1) launch_cfg<128, 128, 4, 2, 3, 2, 392>(p, batch, s); break;
+        case 15: launch_cfg<128, 128, 2, 2, 4, MODE>(p, batch, s); break;
+        case 16: launch_cfg<128, 64, 2, 2, 4, MODE>(p, batch, s); break;
+        case 17: launch_cfg<64, 64, 2, 2, 4, MODE>(p, batch, s); break;
+        case 18: launch_cfg<128, 160, 2, 2, 4, MODE>(p, batch, s); break;
         default: launch_cfg<64, 64, 2, 2, 2, MODE>(p, batch, s); break;
     }
 }
@@ -987,9 +1144,9 @@ static void dispatch_igemm_f8(IGemmP p, int batch, hipStream_t s, int want_cfg) 
     g_pbe_allow_splitk = 1;
     p.splits = 1;
     switch (pl.cfg) {
-        case 3: case 0: case 1: case 2: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
-        case 4: launch_cfg<128, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
-        case 5: case 6: launch_cfg<64, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 3: case 0: case 1: case 2: case 15: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 4: case 16: launch_cfg<128, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
+        case 5: case 6: case 17: launch_cfg<64, 64, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
         case 8: case 7: launch_cfg<128, 320, 2, 4, 2, 0, 0, false, true>(p, batch, s); break;
         default: launch_cfg<128, 160, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
     }

@@ -586,3 +586,37 @@ def test_layernorm_f8(dev):
         err = (deq - ref).abs()
         assert (err <= ref.abs() * 2 ** -4 + sc.cpu()[:, None] * 2 ** -9 + 2e-3).all(), err.max()
         assert (y8.cpu().view(torch.float8_e4m3fn).float().abs().amax(1) == 448.0).all()
+
+
+def test_cross_attention_general_context(dev):
+    """CrossAttention.forward with a multi-token context (attention.py:207-230 in full: separate q / k / v projections, softmax over the
+    context tokens) - not on the Paint-by-Example path (its context is ONE exemplar token) but part of the class's contract - and the
+    self-attention form, against torch fp32."""
+    from ldm.modules.attention import CrossAttention
+    g = _g(77)
+    B, N, Nk, Cq, Cc, heads, dh = 2, 130, 7, 320, 768, 8, 40
+    m = CrossAttention(query_dim=Cq, context_dim=Cc, heads=heads, dim_head=dh)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) / math.sqrt(p_.shape[-1]))
+    x = torch.randn(B, N, Cq, generator=g)
+    ctx = torch.randn(B, Nk, Cc, generator=g)
+
+    def ref(mod, xq, c):
+        c = xq if c is None else c
+        q, k, v = xq @ mod.to_q.weight.t(), c @ mod.to_k.weight.t(), c @ mod.to_v.weight.t()
+        sp = lambda t: t.view(t.shape[0], t.shape[1], heads, dh).permute(0, 2, 1, 3)
+        a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dh ** -0.5, -1) @ sp(v)
+        return a.permute(0, 2, 1, 3).reshape(xq.shape[0], xq.shape[1], heads * dh) @ mod.to_out[0].weight.t() + mod.to_out[0].bias
+    want = ref(m, x, ctx)
+    md = m.to(dev)
+    with torch.no_grad():
+        got = md(x.to(dev), context=ctx.to(dev))
+    _close(got, want, rtol=4e-3, atol=4e-3, what="CrossAttention, 7-token context")
+    ms = CrossAttention(query_dim=Cq, heads=heads, dim_head=dh)
+    with torch.no_grad():
+        for p_ in ms.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) / math.sqrt(p_.shape[-1]))
+        want_s = ref(ms, x, None)
+        got_s = ms.to(dev)(x.to(dev))
+    _close(got_s, want_s, rtol=4e-3, atol=4e-3, what="CrossAttention, self-attention form")

@@ -24,7 +24,7 @@ import torch  # noqa: E402
 from pbe_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-NCFG = 15
+NCFG = 19
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32)
 
 

@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 from pbe_amd import ops  # noqa: E402
 
-NCFG = 15
+NCFG = 19
 SPLITS = (0, 1, 2, 3, 4, 6, 8, 12, 16, 24)        # 0 = the library's own factor for that tile
 
 

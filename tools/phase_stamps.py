@@ -18,7 +18,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["PBE_LIB_PATH"] = os.path.join(ROOT, "tools", "_dbg", "libpbe_hip_stamps.so")
+os.environ["PBE_LIB_PATH"] = os.environ.get("PBE_STAMPS_LIB", os.path.join(ROOT, "tools", "_dbg", "libpbe_hip_stamps.so"))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -68,6 +68,10 @@ def report(spec, s, plan, us, fl, out=sys.stdout):
     for i, n in enumerate(NAMES):
         print(f"   {n:9s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}  "
               f"({100 * np.median(d[:, i]) / np.median(tot):5.1f} % of a workgroup)", file=out)
+    loop = np.maximum(s[:, 4] - s[:, 2], 1).astype(np.float64)        # prime end -> main loop issued
+    for j, n in ((9, "counted vmcnt waits"), (10, "barrier after the fragment reads (ping-pong)"), (11, "barrier closing a k-tile"),
+                 (12, "DMA issue + fragment reads (to lgkmcnt 0 in the ping-pong loop, to issue in the plain loop)"), (13, "MFMA block")):
+        print(f"   wave 0, first + main loop: {n:46s} median {np.median(s[:, j]):9.0f} cycles ({100 * np.median(s[:, j] / loop):5.1f} %)", file=out)
 
 
 def pipeline(keys):
@@ -75,7 +79,7 @@ def pipeline(keys):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import modelbuild
     h = lib.load()
-    buf = torch.zeros(10 << 17, dtype=torch.int64, device=dev)
+    buf = torch.zeros(16 << 17, dtype=torch.int64, device=dev)
     with torch.no_grad():
         model = modelbuild.full_model(dev)
         unet = model.model.diffusion_model
@@ -104,7 +108,7 @@ def pipeline(keys):
                 key = plan[0] + ("|r" if k.get("resid") is not None else "") + ("|geglu" if k.get("act") == ops.ACT_GEGLU else "")
                 if key in keys and key not in got:
                     torch.cuda.synchronize()
-                    got[key] = (buf.cpu().numpy().reshape(-1, 10).copy(), plan)
+                    got[key] = (buf.cpu().numpy().reshape(-1, 16).copy(), plan)
                 return out
             return w
         ops._PLANS = []
@@ -133,7 +137,7 @@ def main():
     if sys.argv[1] == "--pipeline":
         return pipeline(sys.argv[2:])
     h = lib.load()
-    buf = torch.zeros(10 << 17, dtype=torch.int64, device=dev)          # room for 131072 workgroups
+    buf = torch.zeros(16 << 17, dtype=torch.int64, device=dev)          # room for 131072 workgroups
     if os.environ.get("PBE_STAMP_CFG"):                                  # force a tile config (| split << 8) for every spec
         ops.tune(1, int(os.environ["PBE_STAMP_CFG"]))
     for spec in sys.argv[1:]:
@@ -156,7 +160,7 @@ def main():
         torch.cuda.synchronize()
         h.pbe_debug_set_stamps(None)
         plan, ops._PLANS = ops._PLANS[0], None
-        report(spec, buf.cpu().numpy().reshape(-1, 10), plan, us, fl)
+        report(spec, buf.cpu().numpy().reshape(-1, 16), plan, us, fl)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ def main(d, outp):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         if name.startswith("igemm_kernel<"):
             args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
-            klass = "conv3x3_igemm" if args[4] == "1" else "gemm"
+            klass = "conv3x3_igemm" if args[4] in ("1", "2") else "gemm"          # MODE 1 gather / 2 halo-resident conv, 0 dense
         elif name.startswith("attn_kernel<"):
             klass = "attention"
         else:
