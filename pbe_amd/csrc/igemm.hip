@@ -79,10 +79,11 @@ struct IGemmP {
 #define PBE_ACC_STORE() do { } while (0)
 #endif
 
-// Priority of the MFMA block.  PBE_PRIO_MODE (diagnostic builds): 0 = per-block raise (the shipped form), 1 = none,
-// 2 = static: waves 4-7 of an 8-wave tile run at priority 1 for the whole main loop (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
+// Priority of the MFMA block.  PBE_PRIO_MODE: 0 = s_setprio 1 around every MFMA block, 1 = none (shipped: same-device A/B over the
+// whole pipeline, conv class 193.2 -> 191.9 ms, GEMM class unchanged), 2 = static: waves 4-7 of an 8-wave tile at priority 1 for
+// the whole main loop (MI355X_MICROARCH.md, Two waves per SIMD, item 4: 192.1 ms)
 #ifndef PBE_PRIO_MODE
-#define PBE_PRIO_MODE 0
+#define PBE_PRIO_MODE 1
 #endif
 #if PBE_PRIO_MODE == 0
 #define PBE_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
@@ -420,14 +421,13 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             //   period P (tile P), barriers b(2P-1) | b(2P) | b(2P+1):
             //     first half:   group 0 reads tile P's fragments        | group 1 runs the MFMAs of tile P-1
             //     second half:  group 0 runs the MFMAs of tile P        | group 1 reads tile P's fragments
-            //   Every wave issues its DMA pieces of period P - W(P + 2) and, at taps 0 .. LAH-1 of a block with a successor, ONE
-            //   piece of the next block's halo - right behind the fragment reads of its read half, and ends the period by retiring
-            //   what it issued before period P except period P-1's halo piece (counted vmcnt).  The first form of this loop (weight ring of 2, all 7 halo
-            //   pieces at tap 0, pieces with per-lane selects at the HEAD of the read half) spent 1 150 cycles in the read half
-            //   against 680 of MFMAs (tools/phase_stamps.py); spreading the pieces between the MFMAs was worse still.
-            //   RAW: tile P+1 (issued in period P-1) and a halo completed in period 9b+7 have landed for every wave at b(2P+1),
-            //   before their first read.  WAR: W(P+2) lands in tile P-1's slot and block b+1's halo in block b-1's buffer; their
-            //   last reads (group 1, second half of period P-1 / 9b-1) precede b(2P-1).
+            //   The DMA pieces of period P - W(P + 2) and a share of the next block's halo - go out right behind the fragment reads of
+            //   a wave's read half.  The first form of this loop (weight ring of 2, all 7 halo pieces at tap 0, pieces with per-lane
+            //   selects at the HEAD of the read half) spent 1 150 cycles in the read half against 680 of MFMAs
+            //   (tools/phase_stamps.py); spreading the pieces between the MFMAs was worse still (tools/ubench_loop.hip).
+            //   RAW: tile P+1 (issued in period P-1, retired by its issuers at the end of period P) and a halo retired in the second
+            //   half of period 9b+8 have landed at b(2P+1), before their first read.  WAR: W(P+2) lands in tile P-1's slot and block
+            //   b+1's halo in block b-1's buffer; their last reads (group 1, second half of period P-1 / 9b-1) precede b(2P-1).
             static_assert(NW == 8 && BOTH && S == 3 && LAH <= 8, "ping-pong: two waves per SIMD, both k-steps' fragments in registers, weight ring of 3");
             const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
             h16x8 fa[2][TM], fw[2][TN];
@@ -462,11 +462,34 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 }
             };
             const int kt_first = blk0 * 9;
-            const h16* wp[LW];                             // weight pointers of the NEXT tile to issue
+            // The two streams go out through DIFFERENT waves: vmcnt retires in order, so a halo piece (activations no other workgroup
+            // shares: full HBM / Infinity Cache latency, ~2 500 cycles under load) ahead of a weight piece (L2, ~600) in ONE wave's
+            // queue makes the weight tile as late as the halo - with both in every wave the end-of-period wait stalled for ~500
+            // cycles per period.  Group 0 (waves 0-3) issues the weight tiles and retires them every period; group 1 (waves 4-7)
+            // issues the next block's halo, two pieces per period from tap 0 on, and retires it once, at tap 8.
+            constexpr int PWG = PW / 4, LAHG = (PAH + 3) / 4;
+            static_assert(PW % 4 == 0 && LAHG <= 14, "weight pieces split over 4 waves; at most two halo pieces per period over taps 0 .. 6");
+            const int gw = wave & 3;
+            const h16* wp[PWG];                            // group 0: weight pointers of the NEXT tile to issue
+            int hq[LAHG];                                  // group 1: source pixel of this lane's row in halo pieces gw, gw + 4, ...
+#pragma unroll
+            for (int i = 0; i < PWG; ++i)
+                wp[i] = p.W + bz * p.sW + (long)min(n0 + (gw * PWG + i) * 8 + lrow, p.N - 1) * p.ldw + gch * 8 + (long)(kt_first + 2) * 64;
+#pragma unroll
+            for (int i = 0; i < LAHG; ++i) {
+                const int hp = min(gw + 4 * i, PAH - 1) * 8 + lrow;
+                int pix = -1;
+                if (hp < nsub * HPS) {
+                    const int sub = hp / HPS, r = hp - sub * HPS, hy = r / HW2, hx = r - hy * HW2;
+                    const int y = y0 + hy - 1, x = hx - 1;
+                    if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)TW) pix = ((b0 + sub) * p.H + y) * TW + x;
+                }
+                hq[i] = pix;
+            }
             // One MFMA block = the wave's 2 TM TN MFMAs + (a few VALU instructions after every other one) the LDS byte addresses of
             // the fragments of the tile this wave reads NEXT and the bumped weight pointers.
             auto mfmas = [&](int shift_n, int abase_n, int wb_n) {
-                static_assert(TM * TN >= 2 * TM + 1 + LW, "not enough MFMAs to spread the address steps over");
+                static_assert(TM * TN >= 2 * TM + 1 + PWG, "not enough MFMAs to spread the address steps over");
                 PBE_SETPRIO(1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -486,7 +509,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                                         aaddr[0][jj] = abase_n + ar * 128 + ((fq ^ (ar & 7)) << 4);
                                     } else aaddr[1][jj] = aaddr[0][jj] ^ 64;
                                 } else if (st == 2 * TM) { waddr[0] = wb_n + w_rd + rsw; waddr[1] = wb_n + w_rd + (rsw ^ 64); }
-                                else if (st < 2 * TM + 1 + LW) wp[st - 2 * TM - 1] += 64;
+                                else if (st < 2 * TM + 1 + PWG) wp[st - 2 * TM - 1] += 64;
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -495,37 +518,43 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
             // One channel block = 9 periods, UNROLLED: the tap, the ring slot (9 % 3 == 0: a block starts at slot 0), which DMA pieces
             // a period issues and how many may stay in flight at its end are compile-time constants - the run-time form of this
             // loop spent ~25 scalar branches per period on them (and copied the halo pointer arrays around a switch).
-            //   period (blk, tap) issues, right behind its fragment reads: W(kt + 2) into tile kt - 1's slot (unless the block is the
-            //   workgroup's last and tap >= 7) and piece `tap` of block blk + 1's halo (tap < LAH, unless last).
-            //   Its end retires everything issued before it EXCEPT the previous period's halo piece: the weight pieces of a period go
-            //   out before its halo piece and vmcnt retires in order, so that piece (activations no other workgroup shares: full
-            //   HBM / Infinity Cache latency) gets two periods to land.  At tap 8 neither this period nor the last issued one, so a
-            //   block's whole halo has landed before its first read.
+            //   period (blk, tap), right behind the fragment reads: group 0 issues W(kt + 2) into tile kt - 1's slot (unless the block
+            //   is the workgroup's last and tap >= 7) and retires W(kt + 1) at the period's end; group 1 issues halo pieces 2 tap and
+            //   2 tap + 1 of block blk + 1 and retires the whole halo in its read half of tap 8, before the barrier that opens the
+            //   next block.
             auto block = [&](auto LASTC, int blk) {
                 constexpr bool LAST = decltype(LASTC)::value;
                 const int abase = ((blk - blk0) & 1) * (HPA * 128), abase_o = (HPA * 128) - abase;
-                if (!LAST && p.C2 && (blk + 1) * 64 == p.C1) halo_base(blk + 1);
+                const h16* hbase = zsrc;                   // source of halo row 0's chunk for block blk + 1
+                long hcs = 0;
+                if (!LAST) {
+                    const int c0b = (blk + 1) * 64;
+                    const bool first = c0b < p.C1;
+                    hbase = (first ? p.A + c0b : p.A2 + (c0b - p.C1)) + gch * 8;
+                    hcs = first ? p.C1 : p.C2;
+                }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
 #ifdef PBE_STAMPS
                     if (tap == 1 && blk == blk0) PBE_STAMP(3);
 #endif
-                    constexpr int kLW = LW, kLAH = LAH;
-                    const bool w = !LAST || tap < 7, a = !LAST && tap < kLAH, a_prev = !LAST && tap >= 1 && tap - 1 < kLAH;
-                    auto wait_end = [&]() {
-                        if (w) { if (a && a_prev) wait_vmcnt<kLW + 2>(); else if (a || a_prev) wait_vmcnt<kLW + 1>(); else wait_vmcnt<kLW>(); }
-                        else { if (a && a_prev) wait_vmcnt<2>(); else if (a || a_prev) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
-                    };
+                    constexpr int kPWG = PWG;
+                    const bool w = !LAST || tap < 7;
                     PBE_ACC_T0();
                     __builtin_amdgcn_sched_barrier(0);
                     read_frags();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (w) {
+                    if (grp == 0) {
+                        if (w) {
 #pragma unroll
-                        for (int i = 0; i < LW; ++i) PBE_GLDS16(wp[i], wring + ((tap + 2) % 3) * W_BYTES + min(wave + NW * i, PW - 1) * 1024);
+                            for (int i = 0; i < PWG; ++i) PBE_GLDS16(wp[i], wring + ((tap + 2) % 3) * W_BYTES + (gw * PWG + i) * 1024);
+                        }
+                    } else if (!LAST) {
+#pragma unroll
+                        for (int i = 2 * tap; i < 2 * tap + 2; ++i)
+                            if (i < LAHG) PBE_GLDS16(hq[i] >= 0 ? hbase + (long)hq[i] * hcs : zsrc, abuf + abase_o + min(gw + 4 * i, PAH - 1) * 1024);
+                        if (tap == 8) wait_vmcnt<0>();     // the next block's halo has landed (this group has nothing else in flight)
                     }
-                    if (a) issue_a1(abase_o, tap);
-                    if (grp == 1) wait_end();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     PBE_ACC(acc_r_);
@@ -544,7 +573,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                     }
                     PBE_ACC(acc_m_);
                     PBE_ACC_T0();
-                    if (grp == 0) wait_end();
+                    if (grp == 0) { if (w) wait_vmcnt<kPWG>(); else wait_vmcnt<0>(); }      // W(kt + 1) landed; this period's tile may fly
                     PBE_ACC(acc_w_);
                     __builtin_amdgcn_sched_barrier(0);
                     PBE_ACC_T0();
@@ -553,10 +582,8 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                 }
             };
             if (blk0 < blk1) {
-#pragma unroll
-                for (int i = 0; i < LW; ++i) wp[i] = w_row[i] + (long)(kt_first + 2) * 64;
                 frag_addrs(blk0, 0, 0);
-                wait_vmcnt<LW>();                           // halo of block blk0 and W(kt_first) landed; W(kt_first + 1) may be in flight
+                wait_vmcnt<0>();                            // halo of block blk0, W(kt_first) and W(kt_first + 1) landed: every queue starts empty
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier late

@@ -1,14 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-echo skip-tests
-O=gpurun_out/diag3_stamps.txt
-: > $O
-echo skip
-echo skip
-A=gpurun_out/ab3.txt
+A=gpurun_out/ab4.txt
 : > $A
-for v in base new noprio staticprio new noprio staticprio; do
+for v in base new base new; do
   if [ $v = new ]; then unset PBE_LIB_PATH; else export PBE_LIB_PATH=$GRAFT_REPO_ROOT/tools/_dbg/libpbe_hip_$v.so; fi
   echo "== $v" >> $A
   timeout -k 10 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
