@@ -82,7 +82,7 @@ typedef struct pbe_gemm_desc {
     int32_t bias_per_row;
     void* workspace;        /* optional device scratch for split-K partial sums (fp32), or NULL     */
     size_t workspace_bytes; /* any size: the split is clamped to what fits (64 MiB covers the path) */
-    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..14; 10..14 are the halo-resident conv tiles and apply to stride-1 3x3 convs only) | (split-K factor << 8), factor 0 = library's choice */
+    int32_t tile_cfg;       /* -1 = built-in heuristic; else (block-tile config 0..18; 10..14 are the halo-resident conv tiles and apply to stride-1 3x3 convs only, 15..18 deep-ring forms of 3 / 4 / 6 / 9) | (split-K factor << 8), factor 0 = library's choice */
     /* fp8 operands (BASELINE configs[4]): operand_dtype = PBE_DTYPE_F8E4M3 -> A [M, K] and W [N, K] hold OCP e4m3 bytes, lda / ldw /
      * strideA / strideW count BYTES (multiples of 16, K % 16 == 0, no A2), and C = act(alpha * a_scale[m] * w_scale[n] * sum_k A W + ...):
      * a_scale fp32 [M] per row of A (e.g. per token, from pbe_layernorm_f8), w_scale fp32 [N] per row of W (per output channel, from the

@@ -221,6 +221,14 @@ int main() {
     const size_t bytes = (16UL << 20) + 256UL * 32 * 8 * 65536 + 8UL * 32 * 8 * 65536;      // shared panels + one 64 KiB row stream per piece row
     CK(hipMalloc(&src, bytes));
     CK(hipMemset(src, 0, bytes));
+    const bool random_data = getenv("UBENCH_RANDOM") != nullptr;
+    if (random_data) {                                   // fp16 values in [-2, 2): the matrix pipe's power depends on the operands
+        std::vector<unsigned short> h(bytes / 2);
+        unsigned x = 12345u;
+        for (size_t i = 0; i < h.size(); ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(((x >> 16) & 0x83ffu) | 0x3c00u); }
+        CK(hipMemcpy(src, h.data(), bytes, hipMemcpyHostToDevice));
+    }
+    printf("operands: %s\n", random_data ? "random fp16" : "zeros");
     CK(hipMalloc(&out, 256 * 8));
     CK(hipMalloc(&sink, 16));
     run<0, 4>("ping-pong, no DMA (bound of the structure)", src, out, sink);
