@@ -188,6 +188,151 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src,
     if (tid == 0) out[blockIdx.x] = t1 - t0;
 }
 
+// ---- which MFMA shape costs less energy per FLOP?  Same ping-pong loop on a 256 x 128 tile (wave tile 64 x 64: 16 ds_read_b128
+// per k-tile either way), 2 weight pieces + 1 halo piece per wave and k-tile, operands from the shared L2-resident panel:
+//   MF 0: 32 x v_mfma_f32_16x16x32_f16 per wave and k-tile      MF 1: 16 x v_mfma_f32_32x32x16_f16
+// Under the power limit (random operands) the cycle counts are equal and the clock - TFLOP/s - tells the shapes apart.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int MF>
+__global__ __launch_bounds__(512) void shape_kernel(const char* __restrict__ src, int iters, unsigned long long* __restrict__ out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WBS = 128 * 128, NPS = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2, grp = wave >> 2;
+    const int lrow = lane >> 3, gch = (lane & 7) ^ lrow;
+    char* abuf = smem;
+    char* wring = smem + 2 * HALO;
+    const char* ptr[NPS];
+#pragma unroll
+    for (int i = 0; i < NPS; ++i) ptr[i] = src + ((long)((blockIdx.x & 7) * 32 + wave * NPS + i) * 8 + lrow) * 4096 + gch * 16;
+    auto burst = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < NPS; ++i) {
+            char* dst = (i < 2) ? wring + (it % S) * WBS + (wave * 2 + i) * 1024 : abuf + ((it / 9) & 1) * HALO + min(wave + 8 * (it % 7), 48) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ptr[i] + (it & 31) * 128), (lds_void*)dst, 16, 0, 0);
+        }
+    };
+    h8 fa[8], fw[8];
+    float s = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (MF == 0) {
+        f4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4{0, 0, 0, 0};
+        const int fr = lane & 15, fq = lane >> 4, rsw = (fq ^ (fr & 7)) << 4;
+        const int a_rd = (wm * 64 + fr) * 128, w_rd = (wn * 64 + fr) * 128;
+        for (int it = 0; it < iters; ++it) {
+            const char* ab = abuf + ((it / 9) & 1) * HALO + (it % 9) * 128;
+            const char* sw = wring + (it % S) * WBS;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fa[ks * 4 + j] = *reinterpret_cast<const h8*>(ab + a_rd + (rsw ^ (ks * 64)) + j * 16 * 128);
+                    fw[ks * 4 + j] = *reinterpret_cast<const h8*>(sw + w_rd + (rsw ^ (ks * 64)) + j * 16 * 128);
+                }
+            burst(it + 2);
+            if (grp == 1) wait_vm<NPS>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks * 4 + i], fa[ks * 4 + j], acc[i][j], 0, 0, 0);
+            if (grp == 0) wait_vm<NPS>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    } else {
+        f16v acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int fr = lane & 31, fq = lane >> 5;
+        const int a_rd = (wm * 64 + fr) * 128, w_rd = (wn * 64 + fr) * 128;
+        for (int it = 0; it < iters; ++it) {
+            const char* ab = abuf + ((it / 9) & 1) * HALO + (it % 9) * 128;
+            const char* sw = wring + (it % S) * WBS;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {            // k-step of 16: chunks 2 ks + (lane >> 5), swizzled by row & 7
+                const int off = ((2 * ks + fq) ^ (fr & 7)) << 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fa[ks * 2 + j] = *reinterpret_cast<const h8*>(ab + a_rd + off + j * 32 * 128);
+                    fw[ks * 2 + j] = *reinterpret_cast<const h8*>(sw + w_rd + off + j * 32 * 128);
+                }
+            }
+            burst(it + 2);
+            if (grp == 1) wait_vm<NPS>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks * 2 + i], fa[ks * 2 + j], acc[i][j], 0, 0, 0);
+            if (grp == 0) wait_vm<NPS>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][15];
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (s == 12345.f) sink[0] = s;
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+}
+
+template <int MF>
+static void run_shape(const char* name, const char* src, unsigned long long* out, float* sink) {
+    const int iters = 360, blocks = 256;
+    auto k = shape_kernel<MF>;
+    const int lds = 2 * HALO + S * 128 * 128;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    float ms = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, 0, src, iters, out, sink);
+        CK(hipEventRecord(b, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, a, b));
+    }
+    std::vector<unsigned long long> h(blocks);
+    CK(hipMemcpy(h.data(), out, blocks * 8, hipMemcpyDeviceToHost));
+    double cyc = 0;
+    for (int i = 0; i < blocks; ++i) cyc += h[i];
+    cyc /= (double)blocks * iters;
+    const double tf = 256.0 * iters * 2.0 * 256 * 128 * 64 / (ms * 1e-3) / 1e12;
+    printf("%-86s %7.1f cycles per k-tile (MFMA work 1024), %6.1f us, %6.0f TFLOP/s, clock %.2f GHz\n", name, cyc, ms * 1e3, tf, cyc * iters / (ms * 1e3) / 1e3);
+}
+
 template <int STRUCT, int PLACE, int SRC = 0, int FORM = 0>
 static void run(const char* name, const char* src, unsigned long long* out, float* sink) {
     const int iters = 360, blocks = 256;
@@ -245,6 +390,11 @@ int main() {
     run<2, 0>("pipelined in the wave, DMA with k-step 1's reads", src, out, sink);
     run<2, 2>("pipelined in the wave, DMA spread between k-step 1's MFMAs", src, out, sink);
     run<2, 3>("pipelined in the wave, DMA with the next tile's reads", src, out, sink);
+    printf("-- MFMA shape, 256 x 128 tile, wave tile 64 x 64\n");
+    run_shape<0>("ping-pong, v_mfma_f32_16x16x32_f16", src, out, sink);
+    run_shape<1>("ping-pong, v_mfma_f32_32x32x16_f16", src, out, sink);
+    run_shape<0>("ping-pong, v_mfma_f32_16x16x32_f16", src, out, sink);
+    run_shape<1>("ping-pong, v_mfma_f32_32x32x16_f16", src, out, sink);
     printf("-- address form of the pieces\n");
     run<0, 0, 0, 1>("ping-pong, DMA at the head of the read half, form as compiled", src, out, sink);
     run<0, 0, 0, 2>("ping-pong, DMA at the head of the read half, as compiled without the branch", src, out, sink);
