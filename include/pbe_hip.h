@@ -259,7 +259,8 @@ int pbe_planes_to_u8_canvas(const float* src, void* canvas, int32_t H, int32_t W
 
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
- * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1).
+ * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1);
+ * key 5: per-launch choice of the XCD tile order (m fastest where that fetches fewer bytes into the 8 L2s; 0 = always n fastest).
  */
 int pbe_tune(int32_t key, int32_t value);
 

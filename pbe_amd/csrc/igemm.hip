@@ -43,6 +43,7 @@ struct IGemmP {
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
+    int m_fast;     // an XCD's run of tiles walks m fastest (one weight panel, many activation rows) instead of n fastest (launch_cfg)
 #ifdef PBE_STAMPS
     unsigned long long* stamps;     // diagnostic build only (tools/phase_stamps.py): 16 words per workgroup
 #endif
@@ -163,7 +164,11 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int tn_i = tile % tiles_n, tm_i = tile / tiles_n;
+    // Each XCD's L2 fetches what ITS tiles touch.  n fastest: an XCD's run covers few row blocks of A and every column block of
+    // W - right where A is the big operand (64x64 maps).  m fastest: few column blocks of W and every row block of A - right where
+    // W is (16x16 / 8x8 maps: 29 MB of weights against 5 MB of activations; n fastest made all 8 L2s fetch all 29).
+    const int tiles_m = gridDim.x / tiles_n;
+    const int tn_i = p.m_fast ? tile / tiles_m : tile % tiles_n, tm_i = p.m_fast ? tile - tn_i * tiles_m : tile / tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const long bz = blockIdx.y;
 
@@ -1107,6 +1112,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
 }
 
 int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): ping-pong main loop of the halo-resident conv tiles
+int g_pbe_mfast = 1;             // pbe_tune(5, 0/1): let a launch walk its tiles m fastest per XCD when that fetches fewer bytes
 
 template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
@@ -1126,6 +1132,15 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
+    {   // bytes the 8 L2s fetch under either tile order (an XCD owns a contiguous run of tiles_m * tiles_n / 8 tiles)
+        const double a_bytes = MODE != 0 ? 2.0 * (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : 2.0 * p.M * (double)p.K;
+        const double w_bytes = 2.0 * p.N * (double)p.K;
+        const double run = tiles_m * (double)tiles_n / 8.0;
+        auto frac = [](double blocks_touched, int blocks) { const double f = blocks_touched / blocks; return f < 1.0 ? f : 1.0; };
+        const double n_fast = a_bytes * frac(run / tiles_n + 1.0, tiles_m) + w_bytes * frac(run, tiles_n);
+        const double m_fast = w_bytes * frac(run / tiles_m + 1.0, tiles_n) + a_bytes * frac(run, tiles_m);
+        p.m_fast = (g_pbe_mfast && batch == 1 && m_fast < 0.9 * n_fast) ? 1 : 0;
+    }
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;
     pbe_prof_begin(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s);
@@ -1195,6 +1210,7 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
     if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
+    if (key == 5) { g_pbe_mfast = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
