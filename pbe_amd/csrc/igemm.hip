@@ -1,28 +1,34 @@
-// Implicit-GEMM on the gfx950 matrix cores: one kernel body, two activation loaders.
+// Implicit-GEMM on the gfx950 matrix cores: one kernel body, three activation loaders.
 //
 //   MODE 0 (dense)   C[m,n] = sum_k A[m,k] W[n,k]          Linear / 1x1 conv / bmm
 //   MODE 1 (conv3x3) m = (b,oy,ox), k = (ci/cb, tap, ci%cb) NHWC 3x3 conv gather, zero padding, cb % 64 == 0,
 //                                                          optional fused nearest-2x upsample and
 //                                                          two-source channel concat
+//   MODE 2 (conv3x3) the same K order with the activation HALO resident in LDS (stride 1, pad 1, image width 8 .. 128):
+//                    only the weight tile streams per k-tile; the two large tiles run a ping-pong main loop (see there)
 //
 // Structure (CDNA4, wave64):
 //   * workgroup = NWM x NWN waves, block tile BM x BN x 64, each wave owns (BM/NWM) x (BN/NWN) as
 //     16x16 tiles of v_mfma_f32_16x16x32_f16 (two k-steps per k-tile).  The weights are the MFMA "A" operand and the
 //     activations the "B" operand, so an accumulator register quad holds 4 consecutive n for one m.
 //   * tiles stream global -> LDS with global_load_lds_dwordx4 (LDS-DMA, no staging registers) into an S-slot ring
-//     (S = 2 or 3 by tile: S - 1 k-tiles in flight across ONE raw s_barrier per k-tile, retired with counted s_waitcnt vmcnt).
+//     (S = 2 .. 4 by tile: S - 1 k-tiles in flight across ONE raw s_barrier per k-tile, retired with counted s_waitcnt vmcnt).
 //     A k-tile row is 64 halfs = 128 B = one whole cache line: a DMA instruction fetches 8 complete lines.  (Round 1 staged
 //     32 halfs per row; the half-line pieces capped the per-CU fill at 37 GB/s and the MFMA pipe sat idle for 55 % of the
 //     main loop - tools/phase_stamps.py, profiles/r02_phase_stamps_bk32.txt.)
 //   * LDS image: rows of 128 B = 8 chunks of 16 B.  An LDS-DMA instruction writes 64 lanes x 16 B linearly, so the bank
 //     swizzle is applied to the per-lane SOURCE chunk (position p of row r holds global chunk p ^ (r & 7)) and again on
 //     the fragment read: every ds_read_b128 of a 16x16x32 fragment is bank-conflict free in both k-steps.
-//     Out-of-range rows / taps / k read a 16-byte zero block (LDS-DMA cannot mask a lane).
-//   * workgroup ids are remapped so each XCD owns a contiguous run of tiles, n fastest: the
-//     weight panel and the activation rows a run touches stay in that XCD's L2.
+//   * a DMA piece is LEAN (see the loader state): rows beyond M / N are clamped to the last row, the source is a pointer register
+//     plus a scalar k offset, the LDS address an SGPR; padding pixels of the convs, a ragged last k-tile and a k-tile that
+//     straddles the two concatenated sources read a 16-byte zero block through a per-lane select (LDS-DMA cannot mask a lane).
+//   * workgroup ids are remapped so each XCD owns a contiguous run of tiles; the run walks n fastest or m fastest, whichever
+//     fetches fewer bytes into the eight L2s for the launch's operand sizes (launch_cfg).
 //   * small-M / deep-K problems are split along K over gridDim.z with a deterministic fp32 slab reduction.
 //   * epilogue: alpha, bias, row-broadcast vector, activation in fp32 registers -> fp16 C tile in
 //     LDS (one wave-row group at a time) -> whole 16-byte row segments to HBM, residual fused.
+//   * what bounds the big conv tiles on real data is the power limit: cycles removed from the schedule come back
+//     as a lower clock.
 #include <type_traits>
 #include "common.h"
 #include "../../include/pbe_hip.h"
