@@ -453,7 +453,7 @@ def test_groupnorm_small_map_single_launch(dev, B, HW, C):
     _close(ops.groupnorm(x1.to(dev), gamma.to(dev), beta.to(dev), 1e-5, True, x2=x2.to(dev)), ref, rtol=3e-3, what="groupnorm small concat")
 
 
-@pytest.mark.parametrize("cfg", list(range(9)) + [0 | (3 << 8), 4 | (2 << 8)])
+@pytest.mark.parametrize("cfg", list(range(10)) + [15, 16, 17, 18] + [0 | (3 << 8), 4 | (2 << 8), 17 | (2 << 8)])
 def test_every_tile_config_with_every_epilogue(dev, cfg):
     """Each block-tile config (and two forced split-K factors) through the epilogue variants that have their own code path:
     bias + per-sample row vector staged in LDS with 1, 2 and 4 samples per tile (8x8 level: 64 pixels per sample), the
@@ -620,3 +620,54 @@ def test_cross_attention_general_context(dev):
         want_s = ref(ms, x, None)
         got_s = ms.to(dev)(x.to(dev))
     _close(got_s, want_s, rtol=4e-3, atol=4e-3, what="CrossAttention, self-attention form")
+
+
+@pytest.mark.parametrize("K1,K2", [(96, 104), (32, 40), (128, 72), (64, 64), (96, 96)])
+def test_gemm_ragged_k_and_straddling_concat(dev, K1, K2):
+    """The two k-tiles that leave the lean DMA form (igemm.hip, loader state): a last k-tile with K % 64 != 0 (per-lane zeros beyond K)
+    and a k-tile that straddles the two concatenated sources (K1 % 64 != 0), alone and together, with rows off the tile grid (the
+    clamped rows of the lean form) - every dense tile family, forced."""
+    from pbe_amd import ops
+    g = _g(K1 * 7 + K2)
+    M, N = 200, 136
+    a1 = torch.randn(M, K1, generator=g).half()
+    a2 = torch.randn(M, K2, generator=g).half()
+    w = (torch.randn(N, K1 + K2, generator=g) / math.sqrt(K1 + K2)).half()
+    bias = torch.randn(N, generator=g)
+    ref = (torch.cat([a1, a2], 1).float() @ w.float().t() + bias).half().float()
+    try:
+        for cfg in (-1, 3, 6, 9, 1, 17):
+            ops.tune(1, cfg)
+            _close(ops.gemm(a1.to(dev), w.to(dev), bias.to(dev), a2=a2.to(dev)), ref, what=f"gemm K1={K1} K2={K2} cfg {cfg}")
+            ops.tune(1, -1)
+        aw = torch.cat([a1, a2], 1).contiguous()
+        _close(ops.gemm(aw.to(dev), w.to(dev), bias.to(dev)), ref, what=f"gemm K={K1 + K2} single source")
+    finally:
+        ops.tune(1, -1)
+
+
+def test_xcd_tile_order_is_bit_neutral(dev):
+    """The per-launch XCD tile order (m fastest where the weight panel is the big operand: igemm.hip, launch_cfg; pbe_tune key 5) only
+    renumbers which workgroup computes which tile: outputs with the choice on and forced off must be identical, on a deep-weight
+    conv (16x16, 1280 channels: m fastest is chosen), its split-K form, and a GEGLU-shaped GEMM."""
+    from pbe_amd import ops
+    g = _g(4242)
+    x = torch.randn(8, 16, 16, 1280, generator=g).half().to(dev)
+    w = (torch.randn(1280, 1280, 3, 3, generator=g) / math.sqrt(9 * 1280)).half()
+    wp = ops.pack_conv3x3(w.float()).to(dev)
+    b = torch.randn(1280, generator=g).to(dev)
+    a = torch.randn(2048, 1280, generator=g).half().to(dev)
+    wl = (torch.randn(10240, 1280, generator=g) / math.sqrt(1280)).half().to(dev)
+    outs = {}
+    try:
+        for v in (1, 0):
+            ops.tune(5, v)
+            outs[v] = (ops.conv3x3(x, wp, b), ops.gemm(a, wl))
+            ops.tune(1, 10 | (4 << 8))
+            outs[v] += (ops.conv3x3(x, wp, b),)
+            ops.tune(1, -1)
+    finally:
+        ops.tune(5, 1)
+        ops.tune(1, -1)
+    for got, want in zip(outs[1], outs[0]):
+        assert torch.equal(got, want)
