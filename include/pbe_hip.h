@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 6
+#define PBE_ABI_VERSION 7
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -53,6 +53,12 @@ const char* pbe_last_error(void);
 /* sha256 (first 16 hex digits) over the sources and flags the library was built from (pbe_amd/build.py); the ctypes loader
  * recomputes it from the tree and refuses a stale binary instead of silently running old kernels. */
 const char* pbe_source_hash(void);
+/* sizeof() of the three descriptor structs as THIS binary was compiled: a binding checks its own struct layout against them
+ * at load time (pbe_amd/lib.py does; the ctypes stub of INTEGRATION.md section 2 does), so a binding written for an older
+ * ABI hands over a short struct and gets an error instead of an out-of-bounds read. */
+size_t pbe_sizeof_gemm_desc(void);
+size_t pbe_sizeof_conv3x3_desc(void);
+size_t pbe_sizeof_attn_desc(void);
 
 /* ---------------------------------------------------------------------------------------------
  * pbe_gemm_f16 — C[m,n] = act(alpha * sum_k A[m,k] * W[n,k] + bias + rowvec[m / group_rows, n]) + R[m,n]
@@ -91,10 +97,30 @@ typedef struct pbe_gemm_desc {
     const float* w_scale;
     int64_t a_scale_stride, w_scale_stride;
     int32_t operand_dtype;  /* PBE_DTYPE_F16 (0) or PBE_DTYPE_F8E4M3 (1) */
+    /* Extended epilogue (ABI 7; fp16 operands, batch 1, never split-K) - the transformer block's GEMM chain, attention.py:198-252:
+     *  alpha_cols > 0: alpha multiplies columns n < alpha_cols only (q of a fused q | k | v projection, pre-scaled for pbe_attention_f16);
+     *  LayerNorm FOLDED into this GEMM (attention.py:248-252 norm1 / norm3 -> to_q/k/v, ff.net[0].proj): A holds the raw rows x, W must be
+     *    W * gamma, bias must be W beta (+ the layer's bias), ln_colsum[n] = sum_k (W gamma)[n, k] of the fp16 values, and the epilogue forms
+     *    rstd[m] * (acc - mean[m] * ln_colsum[n]) from the row statistics: (sum, sum of squares) of row m = sum over p < ln_parts of the
+     *    float2 ln_stats[(p * ln_stats_ld + m)] (written by the PRODUCER of x through row_stats_out, or by pbe_row_stats_f16);
+     *  row_stats_out: float2 [column tiles][M] partial (sum, sumsq) of THIS launch's stored fp16 output rows, one partial per column tile
+     *    (pbe_gemm_plan's out6[5] tells how many), for the LayerNorm that reads the output;
+     *  VT: columns n >= vt_col0 go to VT[b * vt_bs + (n - vt_col0) * vt_rs + tok] instead of C (row m = b * vt_tokens + tok): V^T for
+     *    pbe_attention_f16 out of the same launch as q | k.  vt_col0 must be a multiple of the tile width the plan picks. */
+    int32_t alpha_cols;
+    const float* ln_stats;
+    int32_t ln_parts;
+    int64_t ln_stats_ld;
+    const float* ln_colsum;
+    float ln_eps;
+    float* row_stats_out;
+    void* VT;
+    int32_t vt_col0, vt_tokens;
+    int64_t vt_bs, vt_rs;
 } pbe_gemm_desc;
 int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream);
 /* Plan / workspace query for the SAME descriptor (nothing is launched): out6 = {tile config index, split-K factor,
- * tile rows BM, tile columns BN, workgroups, 0}; *workspace_needed = bytes of split-K scratch the plan uses (0 when the
+ * tile rows BM, tile columns BN, workgroups, column tiles}; *workspace_needed = bytes of split-K scratch the plan uses (0 when the
  * plan does not split).  A descriptor with a smaller workspace gets a smaller factor, never an error. */
 int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* workspace_needed);
 
@@ -166,7 +192,8 @@ int pbe_layernorm_f8(const void* X, const float* gamma, const float* beta, void*
  *   VT: V transposed, element (b, h, d, n) at VT[b*vt_bs + (h*D+d)*vt_rs + n]  (vt_rs % 8 == 0,
  *       the row must be readable up to the next multiple of 8 past Nk),
  *   O: fp16, element (b, n, h, d) at O[b*o_bs + n*o_rs + h*D + d].
- * D % 8 == 0, D <= 160.
+ * D % 8 == 0, D <= 160.  The softmax reference maximum is deferred (raised when a tile exceeds it by 2^8); the d = 40 form keeps it
+ * as an fp16 number / 64, i.e. |scale * log2(e) * q.k| must stay below 4e6.
  * ------------------------------------------------------------------------------------------ */
 typedef struct pbe_attn_desc {
     const void* Q;
@@ -260,7 +287,8 @@ int pbe_planes_to_u8_canvas(const float* src, void* canvas, int32_t H, int32_t W
 /* pbe_tune — developer knobs for A/B runs in one process (never needed for correctness):
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
  * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1);
- * key 5: per-launch choice of the XCD tile order (m fastest where that fetches fewer bytes into the 8 L2s; 0 = always n fastest).
+ * key 5: per-launch choice of the XCD tile order (m fastest where that fetches fewer bytes into the 8 L2s; 0 = always n fastest);
+ * key 6: attention at d = 40 keeps the softmax reference maximum in the head-dim padding (0 = the multiply-add form).
  */
 int pbe_tune(int32_t key, int32_t value);
 

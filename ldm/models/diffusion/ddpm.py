@@ -35,6 +35,10 @@ class HipLinear(nn.Linear):
     the epilogue).  Used for ``proj_out`` (latent_diffusion.py:112) so that ``model.proj_out(c)`` called the reference's way
     (scripts/inference.py:327) runs the same kernel as the rest of the path instead of an ATen / rocBLAS dispatch."""
 
+    def invalidate_packs(self):
+        """Drop the fp16 pack: writes through ``.data`` (pbe_amd.shard.broadcast_weights_, weights.fill_*) do not bump ``_version``."""
+        self.__dict__.pop("_pk", None)
+
     def _packed(self):
         key = (self.weight.data_ptr(), self.weight._version, self.bias.data_ptr(), self.bias._version)
         c = self.__dict__.get("_pk")

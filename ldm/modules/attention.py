@@ -221,10 +221,15 @@ class BasicTransformerBlock(HipModule):
         p = self.pk()
         x1 = torch.empty((2 * B * N, x2d.shape[1]), dtype=torch.float16, device=x2d.device)
         with ops.pinned_batch_scale(2):              # batch-B launches take the split-K factor of the batch-2B layer: same bits
-            a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
+            if self.linear_fp8:                      # (fp8 GEMMs never split K: nothing to pin for them)
+                a = self.attn1.self_attention_f8(*ops.layernorm_f8(x2d, p.g1, p.b1, p.eps1), B, N)
+            else:
+                a = self.attn1.self_attention(ops.layernorm(x2d, p.g1, p.b1, p.eps1), B, N)
             a1 = self.attn1.pk()
             for half in (0, 1):
                 ops.gemm(a, a1.wo, a1.bo, rowvec=ctx_vec[half * B:(half + 1) * B], group_rows=N, resid=x2d, out=x1[half * B * N:(half + 1) * B * N])
+        if self.linear_fp8:
+            return self.ff.run_f8(*ops.layernorm_f8(x1, p.g3, p.b3, p.eps3), resid=x1)
         return self.ff.run(ops.layernorm(x1, p.g3, p.b3, p.eps3), resid=x1)
 
     def forward(self, x, context=None):

@@ -450,6 +450,38 @@ def gen_full_plms():
     save("full_plms", **out)
 
 
+def gen_full_plms50():
+    """The HEADLINE trajectory at headline size: reference PLMSSampler + reference UNetModel at 320 channels,
+    S = 50, guidance 5, one sample; x after steps 0 / 3 / 25 / 49 and the final latent.  ~51 CFG U-Net pairs on the CPU, twice
+    (reference, then the oracle for the pin)."""
+    UP = "model.diffusion_model."
+    inp = CASES.full_plms50_inputs()
+    rec = CASES.FULL_PLMS50_RECORD
+    unet = build_ref_unet(O.UNET_V1, UP)
+    sd = sd_of(unet, UP)
+    lm = _RefLatentModel(unet)
+    kw = {"images_inpaint": inp["z_inpaint"], "images_mask": inp["mask_lat"]}
+    t0 = time.time()
+    z0, inter = _CpuPLMS(lm).sample(S=inp["steps"], batch_size=1, shape=[4, 64, 64], conditioning=inp["c"], verbose=False,
+                                    unconditional_guidance_scale=inp["scale"], unconditional_conditioning=inp["uc"], eta=0.0,
+                                    x_T=inp["x_T"].clone(), log_every_t=1, test_model_kwargs=kw)
+    print(f"  reference full-size PLMS {inp['steps']} steps: {time.time() - t0:.1f}s, apply_model calls = {lm.calls}", flush=True)
+    assert lm.calls == inp["steps"] + 1
+    xs = inter["x_inter"]
+    out = {f"plms_x_{i}": xs[i + 1] for i in rec}
+    out["plms_latent"] = z0
+    save("full_plms50", **out)                       # written before the (equally long) oracle pass; re-written identically below
+    del unet, lm
+    t0 = time.time()
+    oz, info = O.plms_sample(lambda a, b, cc_: O.unet_forward(sd, a, b, cc_, O.UNET_V1, UP), inp["steps"], inp["x_T"], inp["c"], inp["uc"],
+                             inp["scale"], inp["z_inpaint"], inp["mask_lat"], O.schedule_buffers()["alphas_cumprod"], record=rec)
+    print(f"  oracle full-size PLMS {inp['steps']} steps: {time.time() - t0:.1f}s", flush=True)
+    for i in rec:
+        close(info["x"][i], xs[i + 1], f"full-size PLMS-50 x after step {i}", rtol=2e-3)
+    close(oz, z0, "full-size PLMS-50 final latent", rtol=2e-3)
+    save("full_plms50", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -468,3 +500,5 @@ if __name__ == "__main__":
         gen_full()
     if "full_plms" in todo:
         gen_full_plms()
+    if "full_plms50" in todo:
+        gen_full_plms50()

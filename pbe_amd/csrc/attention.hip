@@ -49,8 +49,20 @@ struct AttnTile {
 // key held by LDS row r of the K tile (middle quads of every 16 rows swapped)
 __device__ __forceinline__ int attn_key_of_row(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <int DP, int QW, int KH>
+// Online softmax with a DEFERRED reference maximum (cdna_hip_programming.md T13): a query keeps a reference m (log2 domain) that is
+// raised only when a tile's largest score exceeds it by more than ATTN_THR; P = exp2(s - m) is then bounded by 2^ATTN_THR = 256
+// instead of 1 - exact in fp16 (11 significant bits at any magnitude, fewer subnormal P), and numerator (P V) and denominator (the
+// ones row of V^T, or the VALU row sum) see the same rounded P.  The rescale of O - and, in the MPAD form, the subtraction of m -
+// leave the per-tile path.
+#define ATTN_THR 8.0f
+
+template <int DP, int QW, int KH, bool MPAD = false>
 __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kernel(const AttnP p) {
+    // MPAD (D == DP - 8: the U-Net's d = 40 heads): the reference maximum rides in the padding of the head dimension.  Column D
+    // of every K row is the constant 64, column D of the (pre-scaled) Q row holds -m / 64 as fp16, so the QK^T MFMA itself returns
+    // s = scale log2e q.k - m and the softmax is max -> exp2 -> cvt with no multiply-add per score (32 of ~130 VALU issues per
+    // unit at d = 40, where the VALU, not the matrix pipe, is the bound).  m is whatever fp16 value the kernel chose (a reference,
+    // not the true maximum: |s| stays within the rounding of m, <= 2^-11 |m|), the factor 64 keeps |m| <= 4.1e6 representable.
     // QW = 32-query sub-blocks per wave (1 or 2).  QW = 2 halves the global K/V traffic, the LDS staging and the
     // barriers per query (more work between barriers); used for long sequences where the grid still fills the chip.
     // KH = 64-key tiles staged per barrier (1 or 2): the 4 waves of a workgroup sit on 4 different SIMDs and
@@ -86,6 +98,11 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     __syncthreads();
     if (ONES && tid < 8 * NSLOT)
         *reinterpret_cast<h16x8*>(smem + (tid >> 3) * BUF + K_BYTES + (DV - 1) * VSTR + (tid & 7) * 16) = one8;
+    if constexpr (MPAD) {                                 // K[:, D] = 64 in every tile image (chunk DC - 1 of a row is never a DMA target)
+        const h16x8 kpad = {(h16)64.f, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < NSLOT * KT; i += 256)
+            *reinterpret_cast<h16x8*>(smem + (i / KT) * BUF + (i % KT) * KSTR + (T::DC - 1) * 16) = kpad;
+    }
 
     // ---- per-lane DMA sources: slot (j*4 + wave)*64 + lane of the tile image, advanced by a constant per tile ----
     const h16* src[NPW];
@@ -148,14 +165,19 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
             const bool ok = (q0 + 32 * i) < p.Nq && d0 < D;
             const h16* qsrc = ok ? Qb + (long)(q0 + 32 * i) * p.q_rs + d0 : p.Q;
             h16x8 v = *reinterpret_cast<const h16x8*>(qsrc);
-            qf[i][ds] = ok ? v : zero8;
+            v = ok ? v : zero8;
+            if constexpr (MPAD) {                            // scale log2e folded into Q (one extra fp16 rounding of q, relative 2^-11)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * p.scale_log2e);
+            }
+            qf[i][ds] = v;
         }
 
     f32x16 o[QW][NDT];
     float m_run[QW], l_run[QW];
 #pragma unroll
     for (int i = 0; i < QW; ++i) {
-        m_run[i] = -INFINITY; l_run[i] = 0.f;
+        m_run[i] = MPAD ? 0.f : -INFINITY; l_run[i] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -223,10 +245,21 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
             }
         }
     };
-    // Online softmax over this lane's 32 keys (+ the other half-wave's 32).  The VALU budget matters (d = 40: 14 MFMAs
-    // per unit vs ~130 VALU ops): the max runs on RAW scores, the scale is folded into the exp2 argument (one FMA),
-    // O is rescaled only when some lane's max grew.  Leaves P^T in pf[]: pf[ks] = keys 16 ks + 8 h + 0..7.
-    auto softmax = [&](int i, int kv0) {
+    // Online softmax over this lane's 32 keys (+ the other half-wave's 32).  The VALU budget matters (d = 40: 14 MFMAs per unit,
+    // 448 matrix-pipe cycles, against what was ~130 VALU issues, ~600 cycles): the max runs on RAW scores, the reference maximum is
+    // deferred (ATTN_THR), the cross-half exchange is one v_permlane32_swap, and in the MPAD form the scores arrive with the scale
+    // and the reference already applied.  Leaves P^T in pf[]: pf[ks] = keys 16 ks + 8 h + 0..7.
+    auto half_max = [&](float v) {                      // max with the other half-wave's value (same query, the other 32 keys)
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned int u = __builtin_bit_cast(unsigned int, v);
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        unsigned int r0 = r[0], r1 = r[1];
+        // hipcc (ROCm 7.2) treats the two results of a swap of one value with itself as EQUAL and folds max(r0, r1) to r0 (checked in
+        // isolation: r0 + 2 r1 compiles to v1 + 2 v1): both results are made opaque before they are combined
+        asm volatile("" : "+v"(r0), "+v"(r1));
+        return fmaxf(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+    };
+    auto softmax = [&](int i, int kv0, bool first) {
         f32x16& s0 = sc[0];
         f32x16& s1 = sc[1];
         if (kv0 + KT > p.Nk) {                          // ragged last tile only (wave-uniform branch)
@@ -242,22 +275,52 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[i], mx * p.scale_log2e);
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run[i]) != 0) {      // some query's running max grew in this wave
-            const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);
-            m_run[i] = m_new;
-            l_run[i] *= alpha;
+        mx = half_max(mx);
+        if constexpr (MPAD) {
+            // s = scale log2e q.k - m_run already.  Raise the reference only when some query of the wave outgrew it by ATTN_THR (or at
+            // the first tile, where the reference is still the arbitrary 0): every quantity at the old reference - O (with its ones
+            // row), and THIS tile's scores - moves to the new one exactly once.
+            if (__builtin_amdgcn_ballot_w64(first || mx > ATTN_THR) != 0) {
+                float tgt = m_run[i] + (first ? mx : fmaxf(mx, 0.f));
+                tgt = fminf(fmaxf(tgt, -4.0e6f), 4.0e6f);                       // -m / 64 must stay an fp16 number
+                const float mref = 64.f * (float)(h16)(tgt * 0.015625f);
+                const float d = mref - m_run[i];
+                m_run[i] = mref;
+                if (!first) {                                                     // (first tile: O is still 0, and 2^-d may overflow)
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    l_run[i] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+                    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
-        }
-        const float neg_m = -m_run[i];
+                        for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
+                }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
-            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
+                for (int r = 0; r < 16; ++r) { s0[r] -= d; s1[r] -= d; }
+                if (h5) qf[i][NDS - 1][0] = (h16)(-mref * 0.015625f);          // column D of this query's row: lanes 32-63, last k-step
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+            }
+        } else {
+            const float ms = mx * p.scale_log2e;
+            if (__builtin_amdgcn_ballot_w64(ms - m_run[i] > ATTN_THR) != 0) {     // (first tile: m_run = -inf)
+                const float m_new = fmaxf(m_run[i], ms);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[i] - m_new);
+                m_run[i] = m_new;
+                l_run[i] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][dt][r] *= alpha;
+            }
+            const float neg_m = -m_run[i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2e, neg_m));
+                s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2e, neg_m));
+            }
         }
         if (!ONES) {
             float psum = 0.f;
@@ -301,7 +364,7 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
             if (PREFV && i == 0) load_v(sv);                 // in flight under the first softmax
             if (PREF && i == QW - 1 && next_k) load_k(next_k);   // the S MFMAs above were the last readers of kf
             __builtin_amdgcn_sched_barrier(0);
-            softmax(i, kv0);
+            softmax(i, kv0, t == 0);
             pv(i, sv);
             __builtin_amdgcn_sched_barrier(0);              // sub-blocks stay sequential: their S / P registers are shared
         }
@@ -353,17 +416,18 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     }
 }
 
-template <int DP, int QW, int KH = 1>
+template <int DP, int QW, int KH = 1, bool MPAD = false>
 static void launch_attn(const AttnP& p, hipStream_t s) {
     constexpr size_t lds = 2 * KH * AttnTile<DP>::BUF;
     static_assert(lds <= 160 * 1024, "attention tile exceeds the LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH, MPAD>), (int)lds);
     dim3 grid(cdiv(p.Nq, 128 * QW), p.B * p.H);
-    hipLaunchKernelGGL((attn_kernel<DP, QW, KH>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_kernel<DP, QW, KH, MPAD>), grid, dim3(256), lds, s, p);
 }
 
 int g_pbe_attn_qw = 0;       // pbe_tune(3, v): 0 = heuristic, 1 / 2 = force queries-per-wave factor
+int g_pbe_attn_mpad = 1;     // pbe_tune(6, 0/1): reference maximum in the head-dim padding (d = 40)
 
 extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(d && d->Q && d->K && d->VT && d->O, "pbe_attention_f16: null operand");
@@ -390,6 +454,7 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     const bool two = g_pbe_attn_qw ? g_pbe_attn_qw == 2 : (blocks2 >= 512 && D <= 80);
     if (D <= 16) launch_attn<16, 1>(p, s);
     else if (D <= 32) launch_attn<32, 1>(p, s);
+    else if (D == 40 && g_pbe_attn_mpad) { if (two) launch_attn<48, 2, 1, true>(p, s); else launch_attn<48, 1, 1, true>(p, s); }     // the U-Net's 64x64 / CFG heads
     else if (D <= 48) { if (g_pbe_attn_qw == 3) launch_attn<48, 2, 2>(p, s); else if (two) launch_attn<48, 2>(p, s); else launch_attn<48, 1>(p, s); }
     else if (D <= 64) { if (two) launch_attn<64, 2>(p, s); else launch_attn<64, 1>(p, s); }
     else if (D <= 80) { if (two) launch_attn<80, 2>(p, s); else launch_attn<80, 1>(p, s); }

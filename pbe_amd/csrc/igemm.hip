@@ -48,6 +48,14 @@ struct IGemmP {
     const float* sa; const float* sw; long ssa, ssw;
     // split-K: gridDim.z slices of the k-tile range, fp32 partial slabs [splits][M][N]
     int splits; float* ws;
+    // extended epilogue of the dense tiles (EX instantiations, the transformer block's GEMM chain; ldm/modules/attention.py:198-252):
+    int alpha_cols;                  // > 0: alpha multiplies columns n < alpha_cols only (q of a fused q | k | v launch, pre-scaled for the attention kernel)
+    const float* ln_stat;            // LayerNorm folded into THIS GEMM: A holds the raw rows x, W = W * gamma, bias = W beta (+ bias), and
+    int ln_parts; long ln_ld;        //   the epilogue forms rstd[m] * (acc - mean[m] * colsum[n]); (sum, sumsq) of row m = sum over ln_parts float2 partials
+    const float* ln_c1; float ln_eps;
+    float* rstat;                    // this launch's OUTPUT rows feed a LayerNorm: per (column tile, row) partial (sum, sumsq) of the stored fp16 values
+    h16* vt; int vt_col0, vt_tok;    // columns n >= vt_col0 are stored TRANSPOSED: vt[b * vt_bs + (n - vt_col0) * vt_rs + tok], m = b * vt_tok + tok
+    long vt_bs, vt_rs;               //   (V^T for the attention kernel from the same launch as q | k)
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
     int m_fast;     // an XCD's run of tiles walks m fastest (one weight panel, many activation rows) instead of n fastest (launch_cfg)
 #ifdef PBE_STAMPS
@@ -127,8 +135,10 @@ __device__ __forceinline__ f32x4 mfma_pair_f8(const h16x8& w, const h16x8& a, f3
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[1], av[1], acc, 0, 0, 0);
 }
 
-template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false>
+template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false, bool EX = false>
 __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, int tiles_n) {
+    // EX (MODE 0, fp16 operands, one-pass epilogue tiles): the extended epilogue - LayerNorm folded in, row statistics out, column-range
+    // alpha, transposed V^T tiles (see IGemmP).  A separate instantiation so that the conv tiles' code and registers do not change.
     // F8 (MODE 0 only): A and W hold OCP e4m3 bytes, a k-tile row of 128 B is 128 k-values; v_mfma_f32_16x16x32_fp8_fp8 runs at
     // the fp16 MFMA's rate, the gain is half the bytes through the fill path that bounds these GEMMs.  The epilogue multiplies
     // by the per-row scale of A and the per-row scale of W (per output column) before bias / activation / residual.
@@ -154,6 +164,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES : S * STAGE;
     static_assert(S >= 2 && S <= 4 && PA % NW == 0 && (PW % NW == 0 || MODE == 2) && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
     static_assert(MODE != 2 || (HPA % 8 == 0 && HPA >= BM), "halo image must hold the tile");
+    static_assert(!EX || (MODE == 0 && !F8), "extended epilogue: dense fp16 tiles only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,13 +344,36 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     const int a_rd = (wm * WM + fr) * 128, w_rd = (wn * WN + fr) * 128;
 
     float* sca = svec + 4 * BN;                       // F8: per-row scale of A for this tile's rows, then per-column scale (W's rows)
-    float* scw = sca + BM;
+    float* scw = sca + BM;                            // EX + LayerNorm fold: sca[row] = rstd, scw[row] = -mean * rstd, lnc[col] = colsum of W * gamma
+    float* lnc = scw + BM;
     auto stage_svec = [&]() {
         if constexpr (F8) {
             for (int idx = tid; idx < BM + BN; idx += NT) {
                 float v = 1.f;
                 if (idx < BM) { if (p.sa && m0 + idx < p.M) v = p.sa[bz * p.ssa + m0 + idx]; sca[idx] = v; }
                 else { const int c = idx - BM; if (p.sw && n0 + c < p.N) v = p.sw[bz * p.ssw + n0 + c]; scw[c] = v; }
+            }
+        }
+        if constexpr (EX) {
+            if (p.ln_stat) {
+                for (int idx = tid; idx < BM + BN; idx += NT) {
+                    if (idx < BM) {
+                        const int m = min(m0 + idx, p.M - 1);
+                        float a = 0.f, q = 0.f;
+                        for (int z = 0; z < p.ln_parts; ++z) {           // fixed order: deterministic
+                            const float2 t = *reinterpret_cast<const float2*>(p.ln_stat + 2 * ((long)z * p.ln_ld + m));
+                            a += t.x; q += t.y;
+                        }
+                        const double inv_k = 1.0 / (double)p.K, mean = (double)a * inv_k;
+                        double var = (double)q * inv_k - mean * mean;
+                        var = var < 0.0 ? 0.0 : var;
+                        const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+                        sca[idx] = rstd; scw[idx] = -(float)mean * rstd;
+                    } else {
+                        const int c = idx - BM;
+                        lnc[c] = n0 + c < p.N ? p.ln_c1[n0 + c] : 0.f;
+                    }
+                }
             }
         }
         if (p.sv_ok && p.splits <= 1) {                  // staged AFTER the first DMAs are in flight: both latencies overlap
@@ -788,6 +822,9 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
     // for the 256-row tiles (128-160 accumulator registers) that many copies push the allocator into scratch, so there the
     // activation stays a uniform run-time branch per quad.
     constexpr bool ARMS = TM * TN * 4 <= 96;
+    constexpr int CLDT = GR + 8;                      // EX: row stride of the transposed C tile (V^T tiles)
+    static_assert(!EX || (ONE_PASS && (size_t)BN * CLDT * 2 <= (size_t)S * STAGE), "extended epilogue: whole C tile (either orientation) in the ring's LDS");
+    const bool vtile = EX && p.vt && n0 >= p.vt_col0;     // uniform: this tile's columns belong to the transposed output
     auto stage = [&](int g, auto FAST, auto ACT) {
         constexpr bool F = decltype(FAST)::value;
         const int A = decltype(ACT)::value >= 0 ? decltype(ACT)::value : p.act;
@@ -833,6 +870,22 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
                     const f32x4 sn = *reinterpret_cast<const f32x4*>(scw + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], add[r]);
+                } else if constexpr (EX) {
+                    const float ali = (p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : al;      // uniform per 16-column group
+                    if (p.ln_stat) {                         // LN(x) W^T = rstd (x W'^T - mean colsum(W')) with W' = W gamma (bias holds W beta + b)
+                        const float rs = sca[g * GR + ml], nm = scw[g * GR + ml];
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnc + nl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(__builtin_fmaf(acc[i][j][r], rs, nm * c1[r]), ali, add[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ali, add[r]);
+                    }
+                    if (vtile) {                             // V^T tile: the C tile goes to LDS transposed, [column][row]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sC[(nl + r) * CLDT + ml] = (h16)v[r];
+                        continue;
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], al, add[r]);
@@ -869,6 +922,57 @@ __global__ void __launch_bounds__(NWM* NWN * 64) igemm_kernel(const IGemmP p, in
         // (tiles whose accumulators stay live across the passes - NG > 1 - have no registers for a deep batch)
         constexpr int UB = !ONE_PASS ? (IT % 2 == 0 ? 2 : 1) : (IT % 5 == 0 ? 5 : (IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : (IT % 2 == 0 ? 2 : 1))));
         const int Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
+        if constexpr (EX && !gg) {
+            if (vtile) {
+                // transposed tile: LDS row = output channel, 16-byte chunks of 8 consecutive tokens -> vt[b][channel][token] rows
+                constexpr int tpr = GR / 8;
+                for (int idx = tid; idx < BN * tpr; idx += NT) {
+                    const int crow = idx / tpr, tch = idx - crow * tpr;
+                    const int m = m0 + tch * 8, c = n0 - p.vt_col0 + crow;
+                    if (m >= p.M || n0 + crow >= p.N) continue;
+                    const int b = m / p.vt_tok, tok = m - b * p.vt_tok;
+                    *reinterpret_cast<h16x8*>(p.vt + (long)b * p.vt_bs + (long)c * p.vt_rs + tok) = *reinterpret_cast<const h16x8*>(sC + crow * CLDT + tch * 8);
+                }
+                return;
+            }
+            if (p.rstat) {
+                // Row statistics for the LayerNorm that reads this output: 8 lanes per row (full 128-byte lines per row and
+                // instruction), each lane sums the STORED fp16 values of its chunks, three xor-shuffles finish the row -
+                // fixed order, no atomics.  Partial (sum, sumsq) of (column tile tn_i, row m) -> rstat[tn_i * M + m].
+                constexpr int RPP = NT / 8, CPL = (CPR + 7) / 8;
+                const int l8 = tid & 7, rr = tid >> 3;
+                for (int r0 = 0; r0 < GR; r0 += RPP) {
+                    const int row = r0 + rr, m = m0 + g * GR + row;
+                    const bool rok = row < GR && m < p.M;
+                    h16x8 v[CPL], r[CPL];
+                    bool ok[CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const int ch = l8 + 8 * c, n = n0 + ch * 8;
+                        ok[c] = rok && ch < CPR && n < p.N;
+                        if (ok[c] && Rb) r[c] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+                    }
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        if (!ok[c]) continue;
+                        const int ch = l8 + 8 * c;
+                        v[c] = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
+                        if (Rb) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[c][e] = (h16)((float)v[c][e] + (float)r[c][e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[c][e]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
+                        *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n0 + ch * 8) = v[c];
+                    }
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                    if (rok && l8 == 0) *reinterpret_cast<float2*>(p.rstat + 2 * ((long)tn_i * p.M + m)) = make_float2(s1, s2);
+                }
+                return;
+            }
+        }
         if (p.vec) {
             for (int it0 = 0; it0 < IT; it0 += UB) {
                 h16x8 v[UB], r[UB];
@@ -1073,18 +1177,25 @@ static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
     return th;
 }
 
+// dense tiles that are instantiated with the extended epilogue (EX): the one-pass 4-wave tiles and 128x320
+static const unsigned kExCfgs = (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 15) | (1u << 16) | (1u << 17) | (1u << 18);
+static inline bool ex_needed(const IGemmP& p) { return p.alpha_cols > 0 || p.ln_stat || p.rstat || p.vt; }
+
 // want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
 // A requested factor is clamped to what the problem allows (batch 1, >= 4 k-tiles of 64 per slice, slabs fit the workspace).
-static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int mode) {
+// (the developer knobs g_pbe_force_cfg / g_pbe_allow_splitk are READ here and never written outside pbe_tune: a caller that must
+//  not split passes ws_bytes = 0, the fallback below passes use_force = false)
+static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg, int mode, bool use_force = true) {
     Plan best{3, 1};
     double best_score = -1.0;
-    const int want = g_pbe_force_cfg >= 0 ? g_pbe_force_cfg : want_cfg;
+    const int want = (use_force && g_pbe_force_cfg >= 0) ? g_pbe_force_cfg : want_cfg;
     const int forced = (want >= 0 && (want & 255) < kNCfg) ? (want & 255) : -1;
     const int want_splits = want >= 0 ? (want >> 8) & 255 : 0;
     const bool shallow = ((p.K + 63) >> 6) < 10;
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];
+        if (ex_needed(p) && (!(kExCfgs >> c & 1) || (p.vt && p.vt_col0 % t.bn))) continue;   // extended epilogue: its tiles only, V^T columns start on a tile
         if (t.hpa && !halo_rows(p, mode, t.bm, t.hpa)) continue;              // a forced halo tile that does not apply falls back below
         if (t.hpa && p.N % 8) continue;
         if (shallow) t.eff = kEffShallow[c];
@@ -1107,20 +1218,15 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
         const double score = t.eff * useful * (0.30 + 0.70 * quant) * split_cost;
         if (score > best_score) { best_score = score; best = Plan{c, sp}; }
     }
-    if (best_score < 0.0 && forced >= 0) {            // the requested tile cannot run this problem: let the heuristic choose
-        IGemmP q = p;
-        const int keep = g_pbe_force_cfg;
-        g_pbe_force_cfg = -1;
-        best = plan_igemm(q, batch, ws_bytes, -1, mode);
-        g_pbe_force_cfg = keep;
-    }
+    if (best_score < 0.0 && forced >= 0)              // the requested tile cannot run this problem: let the heuristic choose
+        best = plan_igemm(p, batch, ws_bytes, -1, mode, false);
     return best;
 }
 
 int g_pbe_pingpong = 1;          // pbe_tune(4, 0/1): ping-pong main loop of the halo-resident conv tiles
 int g_pbe_mfast = 1;             // pbe_tune(5, 0/1): let a launch walk its tiles m fastest per XCD when that fetches fewer bytes
 
-template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false>
+template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false, bool EX = false>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // (ping-pong only where a wave's MFMA phase - (BM/NWM/16) x (BN/NWN/16) x 2 MFMAs - is as long as its read phase: measured
     //  25 % SLOWER on the 128x160 halo tile, whose 20 MFMAs cannot cover 14 fragment reads + 3 DMA issues)
@@ -1130,12 +1236,12 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr int SVR = (ring > c_bytes ? ring : c_bytes) + 4 * BN * sizeof(float) <= 160 * 1024 ? 4 : 3;                              // svec rows (samples per tile)
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + SVR * BN * sizeof(float) +     // + svec[SVR][BN]
-                           (F8 ? (BM + BN) * sizeof(float) : 0);                                                                       // + operand scales
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + (EX ? 4 : SVR) * BN * sizeof(float) +     // + svec[SVR][BN]
+                           (F8 ? (BM + BN) * sizeof(float) : 0) + (EX ? (2 * BM + BN) * sizeof(float) : 0);                            // + operand scales / LayerNorm rows + colsum
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= SVR);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8, EX>), (int)lds);
     const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), batch, p.splits > 1 ? p.splits : 1);
     {   // bytes the 8 L2s fetch under either tile order (an XCD owns a contiguous run of tiles_m * tiles_n / 8 tiles)
@@ -1150,7 +1256,7 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;
     pbe_prof_begin(MODE != 0 ? PBE_K_CONV3 : PBE_K_GEMM, s);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NWM, NWN, MODE, S, HPA, PP, F8, EX>), grid, dim3(NWM * NWN * 64), lds, s, p, tiles_n);
     {   // algorithmic bytes: every operand once (fp16): activations, weights, output, fused residual
         const double nout = p.act == PBE_ACT_GEGLU ? p.N * 0.5 : (double)p.N;
         const double a_el = MODE != 0 ? (double)(p.M / (p.Ho * p.Wo)) * p.H * p.Wd * (p.C1 + p.C2) : (double)p.M * p.K * batch;
@@ -1198,9 +1304,8 @@ static void dispatch_igemm(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, 
 
 // fp8 operands: a subset of the dense tiles (no split-K: the slab reduce does not carry the operand scales)
 static void dispatch_igemm_f8(IGemmP p, int batch, hipStream_t s, int want_cfg) {
-    g_pbe_allow_splitk = 0;
+    p.ws = nullptr;                                   // no workspace: splits_for() returns 1 for every tile
     const Plan pl = plan_igemm(p, batch, 0, want_cfg, 0);
-    g_pbe_allow_splitk = 1;
     p.splits = 1;
     switch (pl.cfg) {
         case 3: case 0: case 1: case 2: case 15: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, true>(p, batch, s); break;
@@ -1211,12 +1316,32 @@ static void dispatch_igemm_f8(IGemmP p, int batch, hipStream_t s, int want_cfg) 
     }
 }
 
+// extended epilogue (LayerNorm fold / row statistics / column-range alpha / V^T tiles): the EX instantiations, never split-K
+static void dispatch_igemm_ex(IGemmP p, int batch, hipStream_t s, int want_cfg) {
+    p.ws = nullptr;
+    const Plan pl = plan_igemm(p, batch, 0, want_cfg, 0);
+    p.splits = 1;
+    switch (pl.cfg) {
+        case 3: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
+        case 4: launch_cfg<128, 64, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
+        case 5: launch_cfg<64, 128, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
+        case 8: launch_cfg<128, 320, 2, 4, 2, 0, 0, false, false, true>(p, batch, s); break;
+        case 9: launch_cfg<128, 160, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
+        case 15: launch_cfg<128, 128, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
+        case 16: launch_cfg<128, 64, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
+        case 17: launch_cfg<64, 64, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
+        case 18: launch_cfg<128, 160, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
+        default: launch_cfg<64, 64, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
+    }
+}
+
 extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 1) { g_pbe_force_cfg = (value >= 0 && (value & 255) < kNCfg) ? value : -1; return PBE_OK; }
     if (key == 2) { g_pbe_allow_splitk = value ? 1 : 0; return PBE_OK; }
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
     if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
     if (key == 5) { g_pbe_mfast = value ? 1 : 0; return PBE_OK; }
+    if (key == 6) { extern int g_pbe_attn_mpad; g_pbe_attn_mpad = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
 
@@ -1248,6 +1373,25 @@ static int fill_gemm(const pbe_gemm_desc* d, IGemmP& p, const char* who) {
     p.vec = (Nout % 8 == 0) && (d->ldc % 8 == 0) && al16(d->C) && (d->strideC % 8 == 0) &&
             (!d->resid || ((d->ldr % 8 == 0) && al16(d->resid) && (d->strideR % 8 == 0)));
     p.ws = (float*)d->workspace;
+    // ---- extended epilogue ----
+    p.alpha_cols = d->alpha_cols;
+    PBE_REQUIRE(d->alpha_cols >= 0 && d->alpha_cols % 4 == 0, "%s: alpha_cols=%d must be a multiple of 4", who, d->alpha_cols);
+    if (d->ln_stats) {
+        PBE_REQUIRE(d->ln_colsum && d->ln_parts >= 1 && d->ln_stats_ld >= d->M && !d->A2 && d->batch == 1 && d->operand_dtype == PBE_DTYPE_F16,
+                    "%s: LayerNorm fold needs ln_colsum, ln_parts >= 1, ln_stats_ld >= M, a single fp16 A source, batch 1", who);
+        p.ln_stat = d->ln_stats; p.ln_parts = d->ln_parts; p.ln_ld = d->ln_stats_ld; p.ln_c1 = d->ln_colsum; p.ln_eps = d->ln_eps;
+    }
+    if (d->row_stats_out) {
+        PBE_REQUIRE(p.vec && d->batch == 1 && !geglu && !d->VT, "%s: row_stats_out needs 16-byte aligned C / resid rows, batch 1, no GEGLU / VT", who);
+        p.rstat = d->row_stats_out;
+    }
+    if (d->VT) {
+        PBE_REQUIRE(d->vt_col0 > 0 && d->vt_col0 < d->N && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && d->M % d->vt_tokens == 0 && d->vt_rs % 8 == 0 &&
+                    d->vt_bs % 8 == 0 && d->vt_rs >= d->vt_tokens && al16(d->VT) && !d->resid && !geglu && d->batch == 1 && p.vec,
+                    "%s: VT needs 0 < vt_col0 < N, vt_tokens %% 8 == 0 dividing M, strides %% 8 == 0, no resid / GEGLU, batch 1", who);
+        p.vt = (h16*)d->VT; p.vt_col0 = d->vt_col0; p.vt_tok = d->vt_tokens; p.vt_bs = d->vt_bs; p.vt_rs = d->vt_rs;
+    }
+    PBE_REQUIRE(!ex_needed(p) || d->operand_dtype == PBE_DTYPE_F16, "%s: the extended epilogue takes fp16 operands", who);
     if (d->operand_dtype == PBE_DTYPE_F8E4M3) {
         // A / W are bytes: [M, K] and [N, K] e4m3, leading dims and batch strides in BYTES.  The loader addresses halfs, so K, K1 and
         // the operand strides are halved (K % 16 == 0 keeps every 16-byte chunk whole).
@@ -1268,6 +1412,7 @@ extern "C" int pbe_gemm_f16(const pbe_gemm_desc* d, pbe_stream_t stream) {
     if (rc != PBE_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (d->operand_dtype == PBE_DTYPE_F8E4M3) dispatch_igemm_f8(p, d->batch, s, d->tile_cfg);
+    else if (ex_needed(p)) dispatch_igemm_ex(p, d->batch, s, d->tile_cfg);
     else dispatch_igemm<0>(p, d->batch, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     PBE_LAUNCH_CHECK("pbe_gemm_f16");
     return PBE_OK;
@@ -1286,7 +1431,9 @@ extern "C" int pbe_gemm_plan(const pbe_gemm_desc* d, int32_t* out6, size_t* work
     IGemmP p;
     const int rc = fill_gemm(d, p, "pbe_gemm_plan");
     if (rc != PBE_OK) return rc;
-    report_plan(p, d->batch, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 0);
+    if (ex_needed(p) || d->operand_dtype == PBE_DTYPE_F8E4M3) p.ws = nullptr;            // these forms never split K
+    report_plan(p, d->batch, p.ws && d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 0);
+    out6[5] = cdiv(p.N, out6[3]);                                                       // column tiles = row-statistics partials per row
     *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
     return PBE_OK;
 }

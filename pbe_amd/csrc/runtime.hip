@@ -22,6 +22,9 @@ extern "C" const char* pbe_last_error(void) { return g_pbe_err; }
 #define PBE_SRC_HASH "unknown"
 #endif
 extern "C" const char* pbe_source_hash(void) { return PBE_SRC_HASH; }
+extern "C" size_t pbe_sizeof_gemm_desc(void) { return sizeof(pbe_gemm_desc); }
+extern "C" size_t pbe_sizeof_conv3x3_desc(void) { return sizeof(pbe_conv3x3_desc); }
+extern "C" size_t pbe_sizeof_attn_desc(void) { return sizeof(pbe_attn_desc); }
 
 // ---- per-class timing: hipEvents recorded on the launch stream around each entry point ---------
 // Off by default (zero overhead: one relaxed load).  bench.py turns it on for ONE profiled pass

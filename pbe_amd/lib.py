@@ -8,7 +8,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBE_LIB_PATH") or os.path.join(_HERE, "libpbe_hip.so")     # PBE_LIB_PATH: diagnostic builds (tools/) only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -21,7 +21,9 @@ class GemmDesc(C.Structure):
                 ("strideA", c_i64), ("strideW", c_i64), ("strideC", c_i64), ("strideR", c_i64),
                 ("batch", c_i32), ("alpha", c_f32), ("act", c_i32), ("bias_per_row", c_i32),
                 ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32),
-                ("a_scale", c_vp), ("w_scale", c_vp), ("a_scale_stride", c_i64), ("w_scale_stride", c_i64), ("operand_dtype", c_i32)]
+                ("a_scale", c_vp), ("w_scale", c_vp), ("a_scale_stride", c_i64), ("w_scale_stride", c_i64), ("operand_dtype", c_i32),
+                ("alpha_cols", c_i32), ("ln_stats", c_vp), ("ln_parts", c_i32), ("ln_stats_ld", c_i64), ("ln_colsum", c_vp), ("ln_eps", c_f32),
+                ("row_stats_out", c_vp), ("VT", c_vp), ("vt_col0", c_i32), ("vt_tokens", c_i32), ("vt_bs", c_i64), ("vt_rs", c_i64)]
 
 
 class Conv3x3Desc(C.Structure):
@@ -43,6 +45,9 @@ SYMBOLS = {
     "pbe_abi_version": (c_i32, []),
     "pbe_last_error": (C.c_char_p, []),
     "pbe_source_hash": (C.c_char_p, []),
+    "pbe_sizeof_gemm_desc": (c_sz, []),
+    "pbe_sizeof_conv3x3_desc": (c_sz, []),
+    "pbe_sizeof_attn_desc": (c_sz, []),
     "pbe_gemm_f16": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "pbe_conv3x3_f16": (c_i32, [C.POINTER(Conv3x3Desc), c_vp]),
     "pbe_gemm_plan": (c_i32, [C.POINTER(GemmDesc), C.POINTER(c_i32), C.POINTER(c_sz)]),
@@ -123,6 +128,9 @@ def load() -> C.CDLL:
         v = lib.pbe_abi_version()
         if v != ABI_VERSION:
             raise PbeError(f"libpbe_hip.so ABI version {v} != expected {ABI_VERSION}")
+        for cls, fn in ((GemmDesc, lib.pbe_sizeof_gemm_desc), (Conv3x3Desc, lib.pbe_sizeof_conv3x3_desc), (AttnDesc, lib.pbe_sizeof_attn_desc)):
+            if C.sizeof(cls) != fn():
+                raise PbeError(f"{cls.__name__}: ctypes layout is {C.sizeof(cls)} bytes, libpbe_hip.so was compiled with {fn()}")
         built, want = lib.pbe_source_hash().decode(), source_hash()
         if built != want and not os.environ.get("PBE_LIB_PATH"):
             raise PbeError(f"libpbe_hip.so was built from other sources (binary {built}, tree {want}): run `python -m pbe_amd.build`")

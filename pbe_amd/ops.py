@@ -59,6 +59,7 @@ _RECORD = None            # set to a dict by tools/autotune.py to collect the sh
 _PLANS = None             # set to a list by tools/layer_diff.py: (key, tile config, split-K factor, BM, BN, workgroups) per GEMM / conv launch
 _PIN_SCALE = 1            # see pinned_batch_scale
 _PIN_CACHE = {}
+_PIN_MISSES = []         # (key, tile, split-K planned at the scaled batch, tile, split-K the sub-batch launch takes instead)
 
 
 class pinned_batch_scale:
@@ -88,19 +89,32 @@ def _plan_of(desc, conv: bool):
 
 
 def _pinned_cfg(desc, key_fn, conv: bool, field: str = "M") -> int:
-    """tile_cfg for `desc` under pinned_batch_scale: the plan of the scaled problem, cached per key."""
+    """tile_cfg for `desc` under pinned_batch_scale: the plan of the scaled problem, cached per (shape key + every other input of
+    the plan: fused residual / output alignment, second source, workspace, forced tile).  If the launch cannot take the pinned
+    (tile, split-K) pair - the library falls back to its heuristic, which changes the fp32 summation order - the miss is recorded
+    in _PIN_MISSES and warned about once per shape (the result is still correct, only not bit-identical to the full batch)."""
     key = key_fn(_PIN_SCALE)
-    hit = _PIN_CACHE.get(key)
+    ck = (key, bool(desc.resid), int(getattr(desc, "ldc", 0)) & 3, int(getattr(desc, "ldr", 0)) & 3, bool(getattr(desc, "A2", None) or getattr(desc, "X2", None)),
+          bool(desc.workspace), int(desc.workspace_bytes), _FORCE_CFG)
+    hit = _PIN_CACHE.get(ck)
     if hit is None:
         big = type(desc).from_buffer_copy(desc)
         if conv:
             big.B = desc.B * _PIN_SCALE
         else:
             setattr(big, field, getattr(desc, field) * _PIN_SCALE)
-        big.tile_cfg = int(_TUNED.get(key, -1))
+        big.tile_cfg = int(_FORCE_CFG) if _FORCE_CFG is not None else int(_TUNED.get(key, -1))
         pl, _ = _plan_of(big, conv)
         hit = pl[0] | (max(1, pl[1]) << 8)
-        _PIN_CACHE[key] = hit
+        small = type(desc).from_buffer_copy(desc)
+        small.tile_cfg = hit
+        got, _ = _plan_of(small, conv)
+        if got[1] != max(1, pl[1]):
+            import warnings
+            _PIN_MISSES.append((key, pl[0], pl[1], got[0], got[1]))
+            warnings.warn(f"pinned_batch_scale({_PIN_SCALE}): {key} plans tile {pl[0]} / split-K {pl[1]} at the scaled batch but the "
+                          f"sub-batch launch runs tile {got[0]} / split-K {got[1]} (different fp32 summation order)")
+        _PIN_CACHE[ck] = hit
     return hit
 
 

@@ -37,9 +37,10 @@ def load_triple(image_path: str, mask_path: str, reference_path: str) -> Dict[st
 
 def load_triple_u8(image_path: str, mask_path: str, reference_path: str) -> Dict[str, np.ndarray]:
     """Decode only (what travels to the GPU): image HWC u8, mask HW u8, exemplar PIL-resized to 224x224 HWC u8."""
-    return {"image": np.asarray(Image.open(image_path).convert("RGB"), dtype=np.uint8),
+    # np.array (owned, writable copies): np.asarray of a PIL image is a read-only view, which torch.from_numpy must not be handed
+    return {"image": np.array(Image.open(image_path).convert("RGB"), dtype=np.uint8),
             "mask": np.array(Image.open(mask_path).convert("L"), dtype=np.uint8),
-            "ref": np.asarray(Image.open(reference_path).convert("RGB").resize((224, 224)), dtype=np.uint8)}
+            "ref": np.array(Image.open(reference_path).convert("RGB").resize((224, 224)), dtype=np.uint8)}
 
 
 def load_triple_device(image_path: str, mask_path: str, reference_path: str, device) -> Dict[str, torch.Tensor]:

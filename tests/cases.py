@@ -79,3 +79,16 @@ def full_plms_inputs():
     m[:, :, 20:44, 12:40] = 0.0
     return {"x_T": torch.randn(1, 4, 64, 64, generator=g), "z_inpaint": torch.randn(1, 4, 64, 64, generator=g) * 0.8, "mask_lat": m,
             "c": torch.randn(1, 1, 768, generator=g), "uc": torch.randn(1, 1, 768, generator=g), "steps": 4, "scale": 5.0}
+
+
+FULL_PLMS50_RECORD = (0, 3, 25, 49)
+
+
+def full_plms50_inputs():
+    """Inputs of tests/golden/full_plms50.npz: ONE sample at configs/v1.yaml size over the HEADLINE trajectory length - 50 PLMS steps,
+    guidance 5 (51 U-Net calls on a guidance pair, plms.py:118-248); x recorded after steps FULL_PLMS50_RECORD."""
+    g = torch.Generator().manual_seed(778)
+    m = torch.ones(1, 1, 64, 64)
+    m[:, :, 14:50, 18:46] = 0.0
+    return {"x_T": torch.randn(1, 4, 64, 64, generator=g), "z_inpaint": torch.randn(1, 4, 64, 64, generator=g) * 0.8, "mask_lat": m,
+            "c": torch.randn(1, 1, 768, generator=g), "uc": torch.randn(1, 1, 768, generator=g), "steps": 50, "scale": 5.0}

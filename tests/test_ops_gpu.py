@@ -343,6 +343,59 @@ def test_attention_softmax_spike(dev):
     _close(got, ref, rtol=4e-3, atol=2e-3, what="attention spike")
 
 
+@pytest.mark.parametrize("D", [40, 80, 64])
+@pytest.mark.parametrize("case", ["first_tile_peak", "negative_start_then_jump", "large_logits", "band_below_threshold", "ragged_jump_in_last_tile"])
+def test_attention_deferred_max_paths(dev, D, case):
+    """The deferred reference maximum (attention.hip, ATTN_THR) and, at d = 40, the reference carried in the head-dim padding: inputs
+    that FORCE each branch (cdna guide rule 26) against a full fp32 reference - the maximum in the first tile and never again, a
+    first tile far below the rest (negative reference, then one big raise), logits of +-3000 log2 units (the fp16 m / 64 form), growth
+    that stays inside the threshold band (no raise: P up to 2^8), and a raise inside the ragged last tile."""
+    from pbe_amd import ops
+    B, H, N = 1, 2, 330 if case == "ragged_jump_in_last_tile" else 384
+    g = _g(17 + D)
+    q = torch.randn(B, N, H * D, generator=g)
+    k = torch.randn(B, N, H * D, generator=g)
+    v = torch.randn(B, N, H * D, generator=g)
+    q4, k4 = q.view(B, N, H, D), k.view(B, N, H, D)
+    if case == "first_tile_peak":
+        k4[0, 5] = q4[0, 40] * 3.0                                    # every query block sees its largest scores in tile 0
+        k4[0, 9] = q4[0, 200] * 3.0
+    elif case == "negative_start_then_jump":
+        k4[0, :64] = -2.5 * torch.sign(q4[0, 100:101]) * torch.ones(64, H, D)      # tile 0 anti-aligned with query 100: its first reference is far below 0
+        k4[0, 300] = q4[0, 100] * 4.0
+    elif case == "large_logits":
+        q4 *= 7.0
+        k4 *= 7.0
+    elif case == "band_below_threshold":
+        for t in range(1, 6):                                          # each tile's best key beats the previous by ~1 log2 unit for query 7
+            k4[0, 64 * t + 3] = q4[0, 7] * (0.25 * t)
+    else:
+        k4[0, 325] = q4[0, 33] * 4.0
+    q, k, v = q.half(), k.half(), v.half()
+    npad = (N + 7) // 8 * 8
+    vt = torch.zeros(B, H * D, npad, dtype=torch.float16)
+    vt[:, :, :N] = v.transpose(1, 2)
+    scale = D ** -0.5
+    q4, k4, v4 = (t.double().reshape(B, N, H, D).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(q4 @ k4.transpose(-1, -2) * scale, -1) @ v4).transpose(1, 2).reshape(B, N, H * D).float()
+    args = (q.to(dev), k.to(dev), vt.to(dev), B, H, N, N, D, scale)
+    kw = dict(q_strides=(N * H * D, H * D), k_strides=(N * H * D, H * D), vt_strides=(H * D * npad, npad))
+    got = ops.attention(*args, **kw)
+    assert torch.isfinite(got).all()
+    # d = 40 with logits of +-400 log2 units: the in-kernel fold of scale log2e into Q rounds q once more (2^-11 per element, i.e.
+    # ~0.03 log2 units on such logits -> 2 % on a P that competes with the row maximum); the product path pre-scales Q in the fp32
+    # epilogue of the projection GEMM instead (pbe_attn_desc.q_prescaled) and the multiply-add form below has no such term
+    loose = case == "large_logits" and D == 40
+    _close(got, ref, rtol=1.2e-2 if loose else 4e-3, atol=2e-3, what=f"attention {case} D={D}")
+    if D == 40:                                                        # the multiply-add form of the same kernel agrees
+        ops.tune(6, 0)
+        try:
+            plain = ops.attention(*args, **kw)
+        finally:
+            ops.tune(6, 1)
+        _close(plain, ref, rtol=4e-3, atol=2e-3, what=f"attention {case} D={D}, multiply-add form")
+
+
 def test_softmax_rows_and_geglu(dev):
     from pbe_amd import ops
     g = _g(12)
