@@ -103,7 +103,7 @@ typedef struct pbe_gemm_desc {
      *    W * gamma, bias must be W beta (+ the layer's bias), ln_colsum[n] = sum_k (W gamma)[n, k] of the fp16 values, and the epilogue forms
      *    rstd[m] * (acc - mean[m] * ln_colsum[n]) from the row statistics: (sum, sum of squares) of row m = sum over p < ln_parts of the
      *    float2 ln_stats[(p * ln_stats_ld + m)] (written by the PRODUCER of x through row_stats_out, or by pbe_row_stats_f16);
-     *  row_stats_out: float2 [column tiles][M] partial (sum, sumsq) of THIS launch's stored fp16 output rows, one partial per column tile
+     *  row_stats_out: float2 [column tiles][row_stats_ld] partial (sum, sumsq) of THIS launch's stored fp16 output rows, one partial per column tile
      *    (pbe_gemm_plan's out6[5] tells how many), for the LayerNorm that reads the output;
      *  VT: columns n >= vt_col0 go to VT[b * vt_bs + (n - vt_col0) * vt_rs + tok] instead of C (row m = b * vt_tokens + tok): V^T for
      *    pbe_attention_f16 out of the same launch as q | k.  vt_col0 must be a multiple of the tile width the plan picks. */
@@ -114,6 +114,7 @@ typedef struct pbe_gemm_desc {
     const float* ln_colsum;
     float ln_eps;
     float* row_stats_out;
+    int64_t row_stats_ld;   /* rows between two column tiles' partials in row_stats_out (>= M; 0 = M) */
     void* VT;
     int32_t vt_col0, vt_tokens;
     int64_t vt_bs, vt_rs;
@@ -179,6 +180,10 @@ int pbe_groupnorm_f16(const void* X, const void* X2, const float* gamma, const f
 int pbe_layernorm_f16(const void* X, const float* gamma, const float* beta, void* Y, int64_t rows,
                       int32_t C, int64_t ldx, int64_t ldy, float eps, pbe_stream_t stream);
 
+/* pbe_row_stats_f16 — out[r] = float2(sum, sum of squares) of the fp16 row X[r, :C]: the one-partial form of the row statistics a
+ * LayerNorm-folding GEMM reads (pbe_gemm_desc.ln_stats, ln_parts = 1) when the producer of X did not emit them (row_stats_out). */
+int pbe_row_stats_f16(const void* X, float* out, int64_t rows, int32_t C, int64_t ldx, pbe_stream_t stream);
+
 /* pbe_layernorm_f8 — the same LayerNorm emitting OCP e4m3 bytes and one fp32 scale per row (BASELINE configs[4]):
  * Y[r, :] = e4m3(LN(X[r, :]) / row_scale[r]), row_scale[r] = max|LN(X[r, :])| / 448; ldy in bytes (multiple of 16).  Feeds the fp8
  * operand form of pbe_gemm_f16 (A = Y, a_scale = row_scale). */
@@ -203,6 +208,8 @@ typedef struct pbe_attn_desc {
     int32_t B, H, Nq, Nk, D;
     int64_t q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
     float scale;
+    int32_t q_prescaled; /* 1: Q already holds scale * log2(e) * q (the projection GEMM applied it in its fp32 epilogue, pbe_gemm_desc.alpha_cols);
+                            `scale` is then ignored */
 } pbe_attn_desc;
 int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream);
 

@@ -28,7 +28,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          # SLP re-pairs the whole accumulator tile into (r0,r2)/(r1,r3) operands for v_pk_fma_f32 (no faster than v_fma_f32 on
          # gfx950, tools/ubench_valu.hip) above the epilogue: a second 128-160 VGPRs, i.e. scratch spills in the 256-row tiles.
-         "igemm.hip": ["-fno-slp-vectorize"]}
+         **{f: ["-fno-slp-vectorize"] for f in ("igemm.hip", "igemm_dense.hip", "igemm_conv.hip", "igemm_halo.hip", "igemm_f8.hip", "igemm_ex.hip")}}
 
 
 def _hipcc() -> str:
@@ -47,7 +47,8 @@ def _stale(target: str, deps) -> bool:
 
 def _compile(src: str, extra) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pbe_hip.h"), os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm_kernel.h"), os.path.join(HERE, "..", "include", "pbe_hip.h"),
+            os.path.abspath(__file__)]
     hash_flag = []
     if src == "runtime.hip":                     # the library's identity: rebuilt whenever ANY source changed
         hash_flag = [f'-DPBE_SRC_HASH="{_libmod.source_hash()}"']
@@ -75,7 +76,7 @@ def build_diagnostic(defines, out_path: str) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         return obj
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(one, SOURCES))
     r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out_path], capture_output=True, text=True)
     if r.returncode != 0:
@@ -90,7 +91,7 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
             os.remove(os.path.join(OBJ, f))
         if os.path.exists(LIB):
             os.remove(LIB)
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, list(extra)), SOURCES))
     if _stale(LIB, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]

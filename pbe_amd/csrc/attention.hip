@@ -26,6 +26,7 @@ struct AttnP {
     int B, H, Nq, Nk, D;
     long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
     float scale_log2e;
+    int q_pre;          // Q already multiplied by scale log2e (then scale_log2e == 1)
 };
 
 #define PBE_GLDS16(gsrc, ldst)                                                                     \
@@ -166,9 +167,11 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
             const h16* qsrc = ok ? Qb + (long)(q0 + 32 * i) * p.q_rs + d0 : p.Q;
             h16x8 v = *reinterpret_cast<const h16x8*>(qsrc);
             v = ok ? v : zero8;
-            if constexpr (MPAD) {                            // scale log2e folded into Q (one extra fp16 rounding of q, relative 2^-11)
+            if constexpr (MPAD) {                            // scale log2e folded into Q: one extra fp16 rounding of q (relative 2^-11) unless
+                if (!p.q_pre) {                              // the projection GEMM already applied it in fp32 (pbe_attn_desc.q_prescaled)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * p.scale_log2e);
+                    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * p.scale_log2e);
+                }
             }
             qf[i][ds] = v;
         }
@@ -445,7 +448,8 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk; p.D = d->D;
     p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.k_bs = d->k_bs; p.k_rs = d->k_rs;
     p.vt_bs = d->vt_bs; p.vt_rs = d->vt_rs; p.o_bs = d->o_bs; p.o_rs = d->o_rs;
-    p.scale_log2e = d->scale * 1.4426950408889634f;
+    p.q_pre = d->q_prescaled ? 1 : 0;
+    p.scale_log2e = p.q_pre ? 1.0f : d->scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     pbe_prof_begin(PBE_K_ATTN, s);
     const int D = d->D;

@@ -325,6 +325,43 @@ extern "C" int pbe_layernorm_f16(const void* X, const float* gamma, const float*
     return PBE_OK;
 }
 
+// Row statistics alone: (sum, sum of squares) of every fp16 row as ONE float2 partial - what the LayerNorm-folding GEMM
+// (pbe_gemm_desc.ln_stats) needs when the producer of x did not emit them from its own epilogue (row_stats_out).
+template <int VPL>
+__global__ void __launch_bounds__(256) row_stats_kernel(const h16* X, float2* out, long rows, int C, long ldx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < C8) {
+            const h16x8 x = *reinterpret_cast<const h16x8*>(X + row * ldx + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) out[row] = make_float2(s1, s2);
+}
+
+extern "C" int pbe_row_stats_f16(const void* X, float* out, int64_t rows, int32_t C, int64_t ldx, pbe_stream_t stream) {
+    PBE_REQUIRE(X && out && rows > 0 && C > 0 && C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldx >= C && ((uintptr_t)X & 15) == 0 && ((uintptr_t)out & 7) == 0,
+                "pbe_row_stats_f16: bad arguments (C %% 8 == 0, <= 2048, aligned rows)");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    pbe_prof_begin(PBE_K_LNORM, s);
+    const int vpl = (C / 8 + 63) / 64;
+#define PBE_RS(V) hipLaunchKernelGGL(row_stats_kernel<V>, grid, block, 0, s, (const h16*)X, (float2*)out, (long)rows, C, (long)ldx)
+    if (vpl <= 1) PBE_RS(1); else if (vpl == 2) PBE_RS(2); else if (vpl == 3) PBE_RS(3); else PBE_RS(4);
+#undef PBE_RS
+    pbe_prof_end(PBE_K_LNORM, s, 2.0 * (double)rows * C);
+    PBE_LAUNCH_CHECK("pbe_row_stats_f16");
+    return PBE_OK;
+}
+
 // LayerNorm with an fp8 (OCP e4m3) output and one scale per row: y8[r, :] = e4m3(LN(x[r, :]) / s[r]), s[r] = max|LN(x[r, :])| / 448.
 // Feeds the fp8 form of pbe_gemm_f16 (a_scale = s): the normalised row never exists in fp16 in HBM (half the bytes of the
 // fp16 LayerNorm's write and of the GEMM's A read).  Same two-pass statistics as layernorm_kernel.

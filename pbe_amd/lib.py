@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32),
                 ("a_scale", c_vp), ("w_scale", c_vp), ("a_scale_stride", c_i64), ("w_scale_stride", c_i64), ("operand_dtype", c_i32),
                 ("alpha_cols", c_i32), ("ln_stats", c_vp), ("ln_parts", c_i32), ("ln_stats_ld", c_i64), ("ln_colsum", c_vp), ("ln_eps", c_f32),
-                ("row_stats_out", c_vp), ("VT", c_vp), ("vt_col0", c_i32), ("vt_tokens", c_i32), ("vt_bs", c_i64), ("vt_rs", c_i64)]
+                ("row_stats_out", c_vp), ("row_stats_ld", c_i64), ("VT", c_vp), ("vt_col0", c_i32), ("vt_tokens", c_i32), ("vt_bs", c_i64), ("vt_rs", c_i64)]
 
 
 class Conv3x3Desc(C.Structure):
@@ -37,7 +37,7 @@ class AttnDesc(C.Structure):
     _fields_ = [("Q", c_vp), ("K", c_vp), ("VT", c_vp), ("O", c_vp),
                 ("B", c_i32), ("H", c_i32), ("Nq", c_i32), ("Nk", c_i32), ("D", c_i32),
                 ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64),
-                ("vt_bs", c_i64), ("vt_rs", c_i64), ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f32)]
+                ("vt_bs", c_i64), ("vt_rs", c_i64), ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f32), ("q_prescaled", c_i32)]
 
 
 # name -> (restype, argtypes): every symbol include/pbe_hip.h declares
@@ -56,6 +56,7 @@ SYMBOLS = {
     "pbe_groupnorm_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "pbe_groupnorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp, c_sz, c_vp]),
     "pbe_layernorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
+    "pbe_row_stats_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp]),
     "pbe_layernorm_f8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
     "pbe_attention_f16": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "pbe_softmax_rows_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
@@ -84,8 +85,9 @@ SYMBOLS = {
 _lib = None
 _lock = threading.Lock()
 
-SOURCES = ["runtime.hip", "igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
-HASHED = [os.path.join("csrc", f) for f in SOURCES] + [os.path.join("csrc", "common.h"), os.path.join("..", "include", "pbe_hip.h"), "build.py"]
+SOURCES = ["runtime.hip", "igemm.hip", "igemm_dense.hip", "igemm_conv.hip", "igemm_halo.hip", "igemm_f8.hip", "igemm_ex.hip", "attention.hip", "norm.hip",
+           "elementwise.hip"]
+HASHED = [os.path.join("csrc", f) for f in SOURCES] + [os.path.join("csrc", "common.h"), os.path.join("csrc", "igemm_kernel.h"), os.path.join("..", "include", "pbe_hip.h"), "build.py"]
 
 
 def source_hash() -> str:

@@ -103,6 +103,11 @@ def _pinned_cfg(desc, key_fn, conv: bool, field: str = "M") -> int:
             big.B = desc.B * _PIN_SCALE
         else:
             setattr(big, field, getattr(desc, field) * _PIN_SCALE)
+            if field == "M":                     # extended epilogue: the scaled problem's statistics planes are as long as its rows
+                if big.ln_stats:
+                    big.ln_stats_ld = max(big.ln_stats_ld, big.M)
+                if big.row_stats_out:
+                    big.row_stats_ld = max(big.row_stats_ld, big.M)
         big.tile_cfg = int(_FORCE_CFG) if _FORCE_CFG is not None else int(_TUNED.get(key, -1))
         pl, _ = _plan_of(big, conv)
         hit = pl[0] | (max(1, pl[1]) << 8)
@@ -173,11 +178,42 @@ def _rows(t: torch.Tensor, what: str) -> Tuple[int, int, int]:
 
 
 # ---------------------------------------------------------------------------------------------
+class RowStats:
+    """Partial (sum, sum of squares) of every row of a [M, C] tensor: `buf` fp32 [parts, ld, 2], as a GEMM epilogue (row_stats=True)
+    or pbe_row_stats_f16 wrote them; what a LayerNorm-folding GEMM consumes (ln=...)."""
+    __slots__ = ("buf", "parts", "ld", "row0")
+
+    def __init__(self, buf, parts, ld, row0=0):
+        self.buf, self.parts, self.ld, self.row0 = buf, parts, ld, row0
+
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 8 * self.row0
+
+
+def row_stats(x: torch.Tensor) -> RowStats:
+    """One-partial row statistics of a contiguous-row fp16 [M, C] tensor (the fallback when x's producer did not emit them)."""
+    _h(x, "row_stats x")
+    M, Cc, ldx = _rows(x, "row_stats x")
+    buf = torch.empty((1, M, 2), dtype=torch.float32, device=x.device)
+    with _timed(f"rs:{M}:{Cc}"):
+        _l.check(_l.load().pbe_row_stats_f16(_p(x), _p(buf), M, Cc, ldx, _stream()), "pbe_row_stats_f16")
+    return RowStats(buf, 1, M)
+
+
+_EX_PARTS = {}
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
          rowvec: Optional[torch.Tensor] = None, group_rows: int = 0, resid: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-         alpha: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         alpha: float = 1.0, bias_per_row: bool = False, out: Optional[torch.Tensor] = None, alpha_cols: int = 0, ln=None,
+         row_stats=False, vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_tokens: int = 0):
     """out[m, n] = act(alpha * sum_k [a | a2][m, k] w[n, k] + bias + rowvec[m // group_rows, n]) + resid[m, n].
-    2-D operands, or 3-D [batch, rows, cols] for a strided batch (w may have batch 1)."""
+    2-D operands, or 3-D [batch, rows, cols] for a strided batch (w may have batch 1).
+
+    Extended epilogue (2-D operands; include/pbe_hip.h, pbe_gemm_desc): alpha_cols = alpha on columns < alpha_cols only;
+    ln = (RowStats of a's rows, colsum fp32 [N], eps): LayerNorm(a) is folded in (w = W * gamma, bias = W beta + b);
+    row_stats = True (or a RowStats to fill, e.g. a slice of a shared buffer): also returns the RowStats of the output rows -> (out, stats);
+    vt [B, N - vt_col0, >= vt_tokens]: columns >= vt_col0 are written transposed there (V^T), `out` then has vt_col0 columns."""
     _h(a, "gemm a"); _h(w, "gemm w")
     batch = 1
     sA = sW = sC = sR = 0
@@ -200,7 +236,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         M, K, lda = _rows(a, "gemm a")
         N, Kw, ldw = _rows(w, "gemm w")
         if out is None:
-            out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), dtype=torch.float16, device=a.device)
+            out = torch.empty((M, vt_col0 if vt is not None else (N // 2 if act == ACT_GEGLU else N)), dtype=torch.float16, device=a.device)
         ldc = _rows(out, "gemm out")[2]
         ldr = 0
         if resid is not None:
@@ -221,18 +257,51 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         ldv = rowvec.stride(0) if rowvec.dim() == 2 else 0
         if group_rows <= 0:
             raise _l.PbeError("gemm: rowvec needs group_rows")
+    ex = bool(alpha_cols or ln is not None or row_stats is not False or vt is not None)
+    kp = "gx" if ex else "g"                   # the extended-epilogue tiles are tuned under their own keys
     d = _l.GemmDesc(_p(a), _p(a2), _p(w), _p(_h(out, "gemm out")), _p(bias), _p(rowvec), _p(resid), M, N, K, K1, lda, lda2, ldw, ldc, ldr,
                     ldv, group_rows, sA, sW, sC, sR, batch, float(alpha), act, 1 if bias_per_row else 0,
-                    _splitk_ws(a.device).data_ptr(), SPLITK_WS_BYTES, _tile_cfg(f"g:{M}:{N}:{K}:{batch}"))
+                    _splitk_ws(a.device).data_ptr(), SPLITK_WS_BYTES, _tile_cfg(f"{kp}:{M}:{N}:{K}:{batch}"))
+    stats = None
+    if ex:
+        if a.dim() != 2:
+            raise _l.PbeError("gemm: the extended epilogue takes 2-D operands")
+        d.alpha_cols = int(alpha_cols)
+        if ln is not None:
+            st, colsum, eps = ln
+            _f(colsum, "gemm ln colsum")
+            if colsum.numel() != N or st.ld - st.row0 < M:
+                raise _l.PbeError("gemm: LayerNorm fold needs colsum [N] and row statistics for every row of a")
+            d.ln_stats, d.ln_parts, d.ln_stats_ld, d.ln_colsum, d.ln_eps = st.ptr(), st.parts, st.ld, _p(colsum), float(eps)
+        if vt is not None:
+            _h(vt, "gemm vt")
+            if vt.dim() != 3 or vt.stride(2) != 1 or vt.shape[1] != N - vt_col0 or vt.shape[0] * vt_tokens != M:
+                raise _l.PbeError(f"gemm: vt must be [M / vt_tokens, N - vt_col0, >= vt_tokens], got {tuple(vt.shape)}")
+            d.VT, d.vt_col0, d.vt_tokens, d.vt_bs, d.vt_rs = _p(vt), int(vt_col0), int(vt_tokens), vt.stride(0), vt.stride(1)
     if _PIN_SCALE != 1:
         if a.dim() == 3:                        # per-sample strided batch (V^T projection): the batch count scales, not M
             d.tile_cfg = _pinned_cfg(d, lambda sc: f"g:{M}:{N}:{K}:{batch * sc}", False, "batch")
         else:
-            d.tile_cfg = _pinned_cfg(d, lambda sc: f"g:{M * sc}:{N}:{K}:1", False)
-    _launch_note(d, f"g:{M}:{N}:{K}:{batch}", False)
-    with _timed(f"g:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}{'v' if rowvec is not None else ''}"):
+            d.tile_cfg = _pinned_cfg(d, lambda sc: f"{kp}:{M * sc}:{N}:{K}:1", False)
+    if row_stats is not False:                  # one partial per column tile of the plan this launch will take
+        ck = (M, N, K, int(d.tile_cfg), bool(resid is not None), bool(vt is not None))
+        parts = _EX_PARTS.get(ck)
+        if parts is None:
+            d.row_stats_out = 8                 # (any non-null value: the plan only needs to know the form)
+            pl, _ = _plan_of(d, False)
+            parts = _EX_PARTS[ck] = pl[5]
+        if isinstance(row_stats, RowStats):
+            stats = row_stats
+            if stats.parts < parts:
+                raise _l.PbeError(f"gemm: row_stats buffer holds {stats.parts} partials, the plan writes {parts}")
+            stats = RowStats(stats.buf, parts, stats.ld, stats.row0)
+        else:
+            stats = RowStats(torch.empty((parts, M, 2), dtype=torch.float32, device=a.device), parts, M)
+        d.row_stats_out, d.row_stats_ld = stats.ptr(), stats.ld
+    _launch_note(d, f"{kp}:{M}:{N}:{K}:{batch}", False)
+    with _timed(f"{kp}:{M}:{N}:{K}:{batch}|a{act}{'r' if resid is not None else ''}{'v' if rowvec is not None else ''}{'L' if ln is not None else ''}{'S' if stats is not None else ''}{'T' if vt is not None else ''}"):
         _l.check(_l.load().pbe_gemm_f16(C.byref(d), _stream()), "pbe_gemm_f16")
-    return out
+    return (out, stats) if row_stats is not False else out
 
 
 def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool) -> Tuple[int, int]:
@@ -402,14 +471,14 @@ def pack_linear_f8(w: torch.Tensor):
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, Nq: int, Nk: int, D: int, scale: float, *,
               q_strides: Tuple[int, int], k_strides: Tuple[int, int], vt_strides: Tuple[int, int],
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
     """softmax(q k^T scale) v -> [B, Nq, H*D].  q/k: element (b,n,h,d) at b*bs + n*rs + h*D + d of the given
     (possibly sliced) tensors; vt: element (b,h,d,n) at b*bs + (h*D+d)*rs + n.  strides = (bs, rs) in elements."""
     _h(q, "attention q"); _h(k, "attention k"); _h(vt, "attention vt")
     if out is None:
         out = torch.empty((B, Nq, H * D), dtype=torch.float16, device=q.device)
     d = _l.AttnDesc(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, D, q_strides[0], q_strides[1], k_strides[0], k_strides[1],
-                    vt_strides[0], vt_strides[1], out.stride(0), out.stride(1), float(scale))
+                    vt_strides[0], vt_strides[1], out.stride(0), out.stride(1), float(scale), 1 if q_prescaled else 0)
     with _timed(f"a:{B}:{H}:{Nq}:{Nk}:{D}"):
         _l.check(_l.load().pbe_attention_f16(C.byref(d), _stream()), "pbe_attention_f16")
     return out
@@ -617,6 +686,17 @@ def conv_kblock(c1: int, c2: int = 0) -> int:
 
 def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1).to(torch.float16).contiguous()
+
+
+def pack_linear_ln(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """Linear(LayerNorm(x)) with the LayerNorm FOLDED into the GEMM (pbe_gemm_desc.ln_stats): returns (W * gamma as fp16 [N, K], the
+    fp32 bias W beta + b, colsum[n] = sum_k of the fp16 values of row n) - LN(x) W^T + b = rstd (x (W gamma)^T - mean colsum) + W beta + b."""
+    w32 = w.detach().reshape(w.shape[0], -1).float()
+    wg = (w32 * gamma.detach().float()[None, :]).to(torch.float16).contiguous()
+    c2 = w32.double() @ beta.detach().double()
+    if bias is not None:
+        c2 = c2 + bias.detach().double()
+    return wg, c2.float().contiguous(), wg.double().sum(1).float().contiguous()
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor):

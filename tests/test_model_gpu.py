@@ -24,6 +24,7 @@ import cases
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = 4e-3
+TRAJ50_TOL = 1e-2          # headline-size 50-step latent; set to <= 3x the measured value (profiles/r03_parity_report.txt)
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
 
 
@@ -282,6 +283,24 @@ def test_full_plms_trajectory_against_reference(dev, golden_dir, full):
     for i, tol in zip(range(inp["steps"]), (4e-3, 6e-3, 8e-3, 1e-2)):
         check(f"v1-size PLMS x after step {i}", inter["x_inter"][i + 1], g[f"plms_x_{i}"], tol)
     check("v1-size PLMS final latent (4 steps)", z0, g["plms_latent"], 1e-2)
+
+
+def test_full_plms50_headline_trajectory_against_reference(dev, golden_dir, full):
+    """The HEADLINE trajectory at headline size: 50 PLMS steps under guidance 5 (51 U-Net calls) on one configs/v1.yaml-size sample
+    against the REFERENCE PLMSSampler + UNetModel (tests/golden/full_plms50.npz, oracle/gen_golden.py --only full_plms50: 9 CPU-minutes
+    of the reference, oracle == reference to 1.3e-6).  x after steps 0 / 3 / 25 / 49 and the final latent."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = np.load(os.path.join(golden_dir, "full_plms50.npz"))
+    inp = cases.full_plms50_inputs()
+    with torch.no_grad():
+        z0, inter = PLMSSampler(full).sample(S=inp["steps"], batch_size=1, shape=[4, 64, 64], conditioning=inp["c"].to(dev), verbose=False,
+                                             unconditional_guidance_scale=inp["scale"], unconditional_conditioning=inp["uc"].to(dev), eta=0.0,
+                                             x_T=inp["x_T"].to(dev), log_every_t=1,
+                                             test_model_kwargs={"images_inpaint": inp["z_inpaint"].to(dev), "images_mask": inp["mask_lat"].to(dev)})
+    assert len(inter["x_inter"]) == inp["steps"] + 1
+    for i in cases.FULL_PLMS50_RECORD:
+        check(f"v1-size PLMS-50 x after step {i}", inter["x_inter"][i + 1], g[f"plms_x_{i}"], TRAJ50_TOL)
+    check("v1-size PLMS-50 final latent (50 steps)", z0, g["plms_latent"], TRAJ50_TOL)
 
 
 def test_full_unet_shared_guidance_prefix(dev, full):

@@ -343,6 +343,104 @@ def test_attention_softmax_spike(dev):
     _close(got, ref, rtol=4e-3, atol=2e-3, what="attention spike")
 
 
+# ---- extended GEMM epilogue: the transformer block's chain (attention.py:198-252) in 5 launches --------------------------------------
+def _ln_ref(x, g, b, eps=1e-5):
+    return F.layer_norm(x.float(), (x.shape[-1],), g, b, eps)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 320, 320), (300, 640, 640), (2048, 1280, 1280), (64, 1920, 320), (1000, 960, 320)])
+def test_gemm_row_statistics_epilogue(dev, M, N, K):
+    """row_stats=True: the epilogue's per-column-tile partial (sum, sumsq) of the STORED fp16 rows, with bias + row vector + residual, summed
+    over the partials, against the same sums taken from the output tensor (fp64), and against pbe_row_stats_f16."""
+    from pbe_amd import ops
+    g = _g(M + N)
+    a, w = _h(torch.randn(M, K, generator=g) * 0.7, dev), _h(torch.randn(N, K, generator=g) / K ** 0.5, dev)
+    bias, resid = torch.randn(N, generator=g).to(dev), _h(torch.randn(M, N, generator=g) * 2 + 0.5, dev)
+    for kw in (dict(), dict(resid=resid), dict(resid=resid, rowvec=_h(torch.randn((M + 63) // 64, N, generator=g), dev), group_rows=64)):
+        plain = ops.gemm(a, w, bias, **kw)
+        y, st = ops.gemm(a, w, bias, row_stats=True, **kw)
+        # same tile, same k order; the two instantiations differ only in how hipcc rounds acc * alpha + bias to fp16 (fused
+        # v_fma_mixlo_f16 = one rounding in the plain tile's arm, v_fma_f32 + v_cvt = two in the extended one): <= 1 ulp on a few elements
+        dy = (y.float() - plain.float()).abs()
+        assert (dy <= 2.0 ** -9 * plain.float().abs().clamp(min=1.0)).all() and (dy > 0).float().mean() < 1e-3
+        got = st.buf[:st.parts].double().sum(0).cpu()                       # [M, 2]
+        want = torch.stack([y.double().sum(1), (y.double() ** 2).sum(1)], 1).cpu()
+        assert torch.allclose(got, want, rtol=2e-6, atol=1e-4), (kw.keys(), (got - want).abs().max())
+        one = ops.row_stats(y)
+        assert one.parts == 1 and torch.allclose(one.buf[0].double().cpu(), want, rtol=2e-6, atol=1e-4)
+        y2, st2 = ops.gemm(a, w, bias, row_stats=True, **kw)
+        assert torch.equal(st.buf, st2.buf)                                 # deterministic (fixed order, no atomics)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 640, 320, 0), (777, 2560, 320, 4), (2048, 2560, 1280, 0), (64, 10240, 1280, 4), (8192, 1920, 640, 0)])
+def test_gemm_layernorm_fold(dev, M, N, K, act):
+    """ln=...: Linear(LayerNorm(x)) with the LayerNorm folded into the GEMM (weights x gain, bias = W beta + b, row statistics applied in
+    the epilogue) against torch fp32 - rows with a large common offset included (mean >> std: the cancellation case of the fold)."""
+    from pbe_amd import ops
+    g = _g(N + K + act)
+    x = torch.randn(M, K, generator=g) * 1.3 + 0.4
+    x[: M // 4] += 6.0                                                      # |mean| = 5 std
+    x = x.half()
+    w, b = torch.randn(N, K, generator=g) / K ** 0.5, 0.1 * torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    h = F.linear(_ln_ref(x, gamma, beta), w, b)
+    if act == 4:
+        Fh = N // 2
+        ref = h[:, :Fh] * F.gelu(h[:, Fh:])
+        wi, bi = torch.stack([w[:Fh], w[Fh:]], 1).reshape(N, K), torch.stack([b[:Fh], b[Fh:]], 1).reshape(N)
+    else:
+        ref, wi, bi = h, w, b
+    wg, c2, c1 = ops.pack_linear_ln(wi, bi, gamma, beta)
+    xd = x.to(dev)
+    for st in (ops.row_stats(xd),):
+        got = ops.gemm(xd, wg.to(dev), c2.to(dev), act=act, ln=(st, c1.to(dev), 1e-5))
+        _close(got, ref, rtol=3e-3, atol=3e-3, what=f"LayerNorm-folded GEMM {M}x{N}x{K} act={act}")
+    old = ops.gemm(ops.layernorm(xd, gamma.to(dev), beta.to(dev), 1e-5), wi.half().to(dev), bi.to(dev), act=act)
+    e_new, e_old = (got.float().cpu() - ref).norm() / ref.norm(), (old.float().cpu() - ref).norm() / ref.norm()
+    assert e_new <= 1.5 * e_old + 1e-4, (e_new, e_old)                      # no worse than the separate-LayerNorm path it replaces
+
+
+@pytest.mark.parametrize("B,N,C,heads", [(2, 256, 320, 8), (8, 64, 1280, 8), (1, 1024, 640, 8), (3, 256, 1280, 8)])
+def test_fused_qkv_projection_and_attention(dev, B, N, C, heads):
+    """ONE launch for to_q | to_k | to_v with norm1 folded in, q pre-scaled by scale log2(e) in the fp32 epilogue and v stored transposed
+    (CrossAttention.self_attention_fused), then the attention core with q_prescaled: against torch fp32 attention on LayerNorm(x)."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from pbe_amd import ops
+    from pbe_amd.weights import fill_module_
+    blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768)
+    fill_module_(blk, prefix=f"tfq{C}.")
+    blk = blk.to(dev).eval()
+    g = _g(B * N + C)
+    x = (torch.randn(B * N, C, generator=g) * 1.5 + 0.3).half()
+    a = blk.attn1
+    xn = _ln_ref(x, blk.norm1.weight.cpu(), blk.norm1.bias.cpu(), blk.norm1.eps)
+    q, k, v = (F.linear(xn, m.weight.cpu().float()).view(B, N, heads, C // heads).transpose(1, 2) for m in (a.to_q, a.to_k, a.to_v))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * a.scale, -1) @ v).transpose(1, 2).reshape(B * N, C)
+    xd = x.to(dev)
+    with torch.no_grad():
+        got = a.self_attention_fused(xd, ops.row_stats(xd), blk.pk(), B, N)
+        old = a.self_attention(ops.layernorm(xd, blk.pk().g1, blk.pk().b1, blk.pk().eps1), B, N)
+    _close(got, ref, rtol=4e-3, atol=3e-3, what=f"fused q|k|v^T + attention B{B} N{N} C{C}")
+    e_new, e_old = (got.float().cpu() - ref).norm() / ref.norm(), (old.float().cpu() - ref).norm() / ref.norm()
+    assert e_new <= 1.5 * e_old + 1e-4, (e_new, e_old)
+
+
+def test_gemm_alpha_cols_and_transposed_columns(dev):
+    """alpha_cols and VT alone (no LayerNorm): C[:, :c0] scaled, columns >= vt_col0 land in VT[b, n - vt_col0, token]."""
+    from pbe_amd import ops
+    g = _g(91)
+    B, T, K, N, c0 = 4, 64, 320, 960, 320
+    a, w, bias = _h(torch.randn(B * T, K, generator=g), dev), _h(torch.randn(N, K, generator=g) / K ** 0.5, dev), torch.randn(N, generator=g).to(dev)
+    ref = F.linear(a.float().cpu(), w.float().cpu())
+    ref[:, :c0] *= 0.37
+    ref = ref + bias.cpu()
+    vt = torch.zeros(B, N - 640, T, dtype=torch.float16, device=dev)
+    out = ops.gemm(a, w, bias, alpha=0.37, alpha_cols=c0, vt=vt, vt_col0=640, vt_tokens=T)
+    assert out.shape == (B * T, 640)
+    _close(out, ref[:, :640], rtol=2e-3, atol=2e-3, what="alpha_cols")
+    _close(vt.transpose(1, 2).reshape(B * T, N - 640), ref[:, 640:], rtol=2e-3, atol=2e-3, what="VT columns")
+
+
 @pytest.mark.parametrize("D", [40, 80, 64])
 @pytest.mark.parametrize("case", ["first_tile_peak", "negative_start_then_jump", "large_logits", "band_below_threshold", "ragged_jump_in_last_tile"])
 def test_attention_deferred_max_paths(dev, D, case):
