@@ -55,7 +55,7 @@ static int fill_gemm(const pbe_gemm_desc* d, IGemmP& p, const char* who) {
     if (d->ln_stats) {
         PBE_REQUIRE(d->ln_colsum && d->ln_parts >= 1 && d->ln_stats_ld >= d->M && !d->A2 && d->batch == 1 && d->operand_dtype == PBE_DTYPE_F16,
                     "%s: LayerNorm fold needs ln_colsum, ln_parts >= 1, ln_stats_ld >= M, a single fp16 A source, batch 1", who);
-        p.ln_stat = d->ln_stats; p.ln_parts = d->ln_parts; p.ln_ld = d->ln_stats_ld; p.ln_c1 = d->ln_colsum; p.ln_eps = d->ln_eps;
+        p.ln_stat = d->ln_stats; p.ln_parts = d->ln_parts; p.ln_ld = d->ln_stats_ld; p.ln_c1 = d->ln_colsum; p.ln_eps = d->ln_eps; p.ln_inv_k = 1.0 / (double)d->K;
     }
     if (d->row_stats_out) {
         PBE_REQUIRE(p.vec && d->batch == 1 && !geglu && !d->VT, "%s: row_stats_out needs 16-byte aligned C / resid rows, batch 1, no GEGLU / VT", who);

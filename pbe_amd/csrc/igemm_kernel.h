@@ -53,7 +53,7 @@ struct IGemmP {
     int alpha_cols;                  // > 0: alpha multiplies columns n < alpha_cols only (q of a fused q | k | v launch, pre-scaled for the attention kernel)
     const float* ln_stat;            // LayerNorm folded into THIS GEMM: A holds the raw rows x, W = W * gamma, bias = W beta (+ bias), and
     int ln_parts; long ln_ld;        //   the epilogue forms rstd[m] * (acc - mean[m] * colsum[n]); (sum, sumsq) of row m = sum over ln_parts float2 partials
-    const float* ln_c1; float ln_eps;
+    const float* ln_c1; float ln_eps; double ln_inv_k;
     long rstat_ld;
     float* rstat;                    // this launch's OUTPUT rows feed a LayerNorm: per (column tile, row) partial (sum, sumsq) of the stored fp16 values
     h16* vt; int vt_col0, vt_tok;    // columns n >= vt_col0 are stored TRANSPOSED: vt[b * vt_bs + (n - vt_col0) * vt_rs + tok], m = b * vt_tok + tok
@@ -140,7 +140,10 @@ __device__ __forceinline__ f32x4 mfma_pair_f8(const h16x8& w, const h16x8& a, f3
 // (the 4-wave tiles of the extended epilogue live two workgroups per CU - two waves per SIMD, 256 registers each: declared, so the
 //  allocator does not take the 260+ it would like for the 128x160 tile and halve the occupancy)
 template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false, bool EX = false>
-__global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2) ? 2 : 1) igemm_kernel(const IGemmP p, int tiles_n) {
+#ifndef PBE_EX_MINWAVES
+#define PBE_EX_MINWAVES 2
+#endif
+__global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2) ? PBE_EX_MINWAVES : 1) igemm_kernel(const IGemmP p, int tiles_n) {
     // EX (MODE 0, fp16 operands, one-pass epilogue tiles): the extended epilogue - LayerNorm folded in, row statistics out, column-range
     // alpha, transposed V^T tiles (see IGemmP).  A separate instantiation so that the conv tiles' code and registers do not change.
     // F8 (MODE 0 only): A and W hold OCP e4m3 bytes, a k-tile row of 128 B is 128 k-values; v_mfma_f32_16x16x32_fp8_fp8 runs at
@@ -368,10 +371,11 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
                             const float2 t = *reinterpret_cast<const float2*>(p.ln_stat + 2 * ((long)z * p.ln_ld + m));
                             a += t.x; q += t.y;
                         }
-                        const double inv_k = 1.0 / (double)p.K, mean = (double)a * inv_k;
-                        double var = (double)q * inv_k - mean * mean;
-                        var = var < 0.0 ? 0.0 : var;
-                        const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+                        // (only the cancelling subtraction runs in fp64 - three full-rate operations; an fp64 divide + square root per row cost
+                        //  the workgroup ~1 500 cycles of a 8 000-cycle K = 320 tile)
+                        const double mean = (double)a * p.ln_inv_k;
+                        const float var = (float)((double)q * p.ln_inv_k - mean * mean);
+                        const float rstd = __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + p.ln_eps);
                         sca[idx] = rstd; scw[idx] = -(float)mean * rstd;
                     } else {
                         const int c = idx - BM;
@@ -836,10 +840,29 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
         // into a second full set of accumulator registers and the 256-row tiles spill (measured: 30 us of epilogue per tile).
         float al = p.alpha;
         asm volatile("" : "+s"(al));
+        float ln_rs[EX ? TM : 1], ln_nm[EX ? TM : 1];      // EX + LayerNorm fold: this lane's rows' rstd and -mean rstd (LDS, read once)
+        if constexpr (EX) {
+            if (p.ln_stat) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
+                    ln_rs[j] = sca[g * GR + ml]; ln_nm[j] = scw[g * GR + ml];
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int nl = wn * WN + i * 16 + fq * 4;
             const int n = n0 + nl;
+            float ali = al, c1a[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EX) {
+                ali = (p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : al;
+                if (p.ln_stat) {
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnc + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c1a[r] = ali * c1[r];
+                }
+            }
             float bn[4] = {0.f, 0.f, 0.f, 0.f};
             if (F) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(svec + nl);
@@ -875,12 +898,10 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], add[r]);
                 } else if constexpr (EX) {
-                    const float ali = (p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : al;      // uniform per 16-column group
                     if (p.ln_stat) {                         // LN(x) W^T = rstd (x W'^T - mean colsum(W')) with W' = W gamma (bias holds W beta + b)
-                        const float rs = sca[g * GR + ml], nm = scw[g * GR + ml];
-                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnc + nl);
+                        const float ars = ali * ln_rs[j];    //   alpha (rstd acc - mean rstd colsum) + bias  =  acc (alpha rstd) + ((-mean rstd) (alpha colsum) + bias)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(__builtin_fmaf(acc[i][j][r], rs, nm * c1[r]), ali, add[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ars, __builtin_fmaf(ln_nm[j], c1a[r], add[r]));
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ali, add[r]);
@@ -943,32 +964,37 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
                 // Row statistics for the LayerNorm that reads this output: 8 lanes per row (full 128-byte lines per row and
                 // instruction), each lane sums the STORED fp16 values of its chunks, three xor-shuffles finish the row -
                 // fixed order, no atomics.  Partial (sum, sumsq) of (column tile tn_i, row m) -> rstat[tn_i * M + m].
-                constexpr int RPP = NT / 8, CPL = (CPR + 7) / 8;
+                constexpr int RPP = NT / 8, CPL = (CPR + 7) / 8, NIT = (GR + RPP - 1) / RPP;
                 const int l8 = tid & 7, rr = tid >> 3;
-                for (int r0 = 0; r0 < GR; r0 += RPP) {
-                    const int row = r0 + rr, m = m0 + g * GR + row;
-                    const bool rok = row < GR && m < p.M;
-                    h16x8 v[CPL], r[CPL];
-                    bool ok[CPL];
+                h16x8 r[NIT][CPL];
+                if (Rb) {                                    // every residual load of the thread first: one exposed round trip, not NIT
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) {
-                        const int ch = l8 + 8 * c, n = n0 + ch * 8;
-                        ok[c] = rok && ch < CPR && n < p.N;
-                        if (ok[c] && Rb) r[c] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+                    for (int it = 0; it < NIT; ++it) {
+                        const int row = it * RPP + rr, m = m0 + g * GR + row;
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            const int ch = l8 + 8 * c, n = n0 + ch * 8;
+                            if (row < GR && m < p.M && ch < CPR && n < p.N) r[it][c] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+                        }
                     }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int row = it * RPP + rr, m = m0 + g * GR + row;
+                    const bool rok = row < GR && m < p.M;
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) {
-                        if (!ok[c]) continue;
-                        const int ch = l8 + 8 * c;
-                        v[c] = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
+                        const int ch = l8 + 8 * c, n = n0 + ch * 8;
+                        if (!(rok && ch < CPR && n < p.N)) continue;
+                        h16x8 v = *reinterpret_cast<const h16x8*>(sC + row * CLD + ch * 8);
                         if (Rb) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[c][e] = (h16)((float)v[c][e] + (float)r[c][e]);
+                            for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r[it][c][e]);
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { const float f = (float)v[c][e]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
-                        *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n0 + ch * 8) = v[c];
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
+                        *reinterpret_cast<h16x8*>(Cb + (long)m * p.ldc + n) = v;
                     }
 #pragma unroll
                     for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--merge", default="", help="start from this table; shapes measured here replace their entries")
     ap.add_argument("--image-size", type=int, default=512, help="768 = BASELINE configs[4] geometry")
     ap.add_argument("--precision", default="fp16", choices=("fp16", "fp8"))
+    ap.add_argument("--only-prefix", default="", help="keep only shape keys with this prefix (gx: = the extended-epilogue GEMMs); candidates are then its tiles only")
     a = ap.parse_args()
     import cases
     import modelbuild
@@ -79,6 +80,8 @@ def main():
             inp = {k: v.to(dev) for k, v in cases.synthetic_triples(B, a.image_size).items()}
             one_pass(model, inp, a.steps, -1)                                   # warm: packs, workspaces
             cands = [cfg | (sp << 8) for cfg in range(NCFG) for sp in SPLITS]
+            if a.only_prefix == "gx:":                                            # extended epilogue: its instantiated tiles, never split-K
+                cands = [cfg | (1 << 8) for cfg in (3, 4, 5, 6, 8, 9, 15, 16, 17, 18)]
             data = {}                                                            # key -> {(cfg, splits): [us, ...]}
             counts = {}
             for rep in range(a.reps):
@@ -93,6 +96,8 @@ def main():
             base = one_pass(model, inp, a.steps, -1)                            # the built-in heuristic, for the report
             tot_h = tot_b = 0.0
             for key in sorted(data):
+                if a.only_prefix and not key.startswith(a.only_prefix):
+                    continue
                 med = {eff: statistics.median(v) for eff, v in data[key].items()}
                 best = min(med, key=med.get)
                 table[key] = best[0] | (best[1] << 8)
