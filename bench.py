@@ -45,6 +45,9 @@ def parse_args(argv=None):
     ap.add_argument("--image-size", type=int, default=512, choices=(512, 768), help="768 = BASELINE configs[4] geometry (96x96 latents)")
     ap.add_argument("--precision", default="fp16", choices=("fp16", "fp8"),
                     help="fp8 = BASELINE configs[4]: e4m3 operands for the LayerNorm-fed projections (pbe_amd.precision); not the headline config")
+    ap.add_argument("--weights", default="broadcast", choices=("broadcast", "local"),
+                    help="N > 1: rank 0 synthesises and broadcasts over RCCL (default, the north-star's step) or every rank synthesises its own copy")
+    ap.add_argument("--no-batch16", action="store_true", help="skip the extra BASELINE configs[2]-size (batch 16) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -103,16 +106,19 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_model(device, rank, world):
-    """Rank 0 synthesises the weights; other ranks allocate empty storage and receive them through
-    ONE bucketed RCCL broadcast."""
+def build_model(device, rank, world, weights="broadcast"):
+    """weights = "broadcast" (the north-star's step): rank 0 synthesises the name-seeded weights, the other ranks
+    allocate empty storage and receive them through ONE bucketed RCCL broadcast (fp32 masters, 1 GiB buckets over xGMI);
+    "local": every rank synthesises its own copy concurrently (name-seeded = bit-identical by construction; no rank waits for rank 0's
+    14-23 s of CPU work) and a 2-number checksum all-reduce proves the copies agree.  Either way the packs are built per rank."""
     from ldm.util import instantiate_from_config, load_yaml_config
-    from pbe_amd.shard import broadcast_weights_
+    from pbe_amd.shard import broadcast_weights_, weights_checksum
     from pbe_amd.weights import fill_latent_diffusion_
     cfg = load_yaml_config(os.path.join(ROOT, "configs", "v1.yaml"))["model"]
     cpu_sd = None
     t0 = time.time()
-    if rank == 0:
+    info = {"weights": weights if world > 1 else "single rank"}
+    if rank == 0 or weights == "local":
         model = instantiate_from_config(cfg)
         fill_latent_diffusion_(model)
         if world == 1:
@@ -124,14 +130,18 @@ def build_model(device, rank, world):
         model = model.to_empty(device=device).eval()
         model.register_schedule(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
         model = model.to(device)
-    log(f"model built in {time.time() - t0:.1f}s")
+    info["build_s"] = time.time() - t0
+    log(f"model built in {info['build_s']:.1f}s")
     if world > 1:
         t0 = time.time()
-        info = broadcast_weights_(model, src=0)
-        torch.cuda.synchronize()
-        log(f"weight broadcast: {info['bytes'] / 1e9:.2f} GB in {int(info['messages'])} messages, {time.time() - t0:.2f}s")
+        if weights == "broadcast":
+            b = broadcast_weights_(model, src=0)
+            torch.cuda.synchronize()
+            info.update(broadcast_gb=b["bytes"] / 1e9, broadcast_messages=int(b["messages"]), broadcast_s=time.time() - t0)
+            log(f"weight broadcast: {info['broadcast_gb']:.2f} GB in {info['broadcast_messages']} messages, {info['broadcast_s']:.2f}s")
+        info["weights_identical_on_all_ranks"] = weights_checksum(model)
     model.prepare()
-    return model, cpu_sd
+    return model, cpu_sd, info
 
 
 def cpu_info():
@@ -222,13 +232,19 @@ def main():
     backend = os.environ.get("PBE_DIST_BACKEND", "nccl")
     if a.rehearse_launch:        # tests only (tests/test_shard_gloo.py): the launch / rendezvous / relay path without a GPU
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        per_rank = [10.0 * (rank + 1)]
         if world > 1:
             dist.init_process_group("gloo")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            mine = torch.tensor([10.0 * (rank + 1)], dtype=torch.float64)          # the per-rank timing exchange of the real run
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [float(x.item()) for x in allr]
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"rehearsal": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": a.steps, "warmup": a.warmup}), flush=True)
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": a.steps, "warmup": a.warmup,
+                              "per_rank_ms": {"min": min(per_rank), "max": max(per_rank), "all": per_rank}}), flush=True)
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -249,7 +265,7 @@ def main():
     from pbe_amd.pipeline import inpaint
     from pbe_amd.shard import gather_images
 
-    model, cpu_sd = build_model(device, rank, world)
+    model, cpu_sd, build_info = build_model(device, rank, world, a.weights)
     if a.precision == "fp8":
         from pbe_amd.precision import set_linear_precision
         set_linear_precision(model, "fp8")
@@ -274,9 +290,18 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             one_step()
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0                     # this rank's K steps, before it waits for the others
         fence()
         elapsed = time.perf_counter() - t0
+        per_rank_ms = [1e3 * elapsed / a.steps]
         if world > 1:
+            # every rank's own time for its K steps (before the closing barrier it would equal the slowest): a slow (power-capped) device
+            # shows up as ONE large entry, a code-level scaling loss as all of them growing with N
+            mine = torch.tensor([own_elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank_ms = [1e3 * float(x.item()) / a.steps for x in allr]
             t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -293,6 +318,22 @@ def main():
             ops.prof_enable(False)
             prof = ops.prof_collect()
             ops.prof_reset()
+
+        # ---- BASELINE configs[2] geometry (batch 16 per GPU, same everything else): reported beside the headline, never as `value` ----
+        b16 = None
+        if world == 1 and rank == 0 and not a.no_batch16 and a.image_size == 512 and a.precision == "fp16" and a.plms_steps == 50 and B != 16:
+            inp16 = {k: v.to(device) for k, v in cases.synthetic_triples(16, 512).items()}
+            run16 = lambda: inpaint(model, inp16["image"], inp16["mask"], inp16["ref"], steps=a.plms_steps, scale=a.scale, x_T=inp16["x_T"],      # noqa: E731
+                                    post_eps=inp16["post_eps"])
+            run16()
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            for _ in range(2):
+                run16()
+            torch.cuda.synchronize()
+            t16 = (time.perf_counter() - t16) / 2
+            b16 = {"per_gpu_batch": 16, "value": 16 / t16, "unit": "images/sec", "ms_per_step": 1e3 * t16, "steps": 2, "warmup": 1}
+            del inp16
 
     if rank != 0:
         if world > 1:
@@ -324,8 +365,20 @@ def main():
                    "parallelism": f"batch-sharded x{world}, no per-step collective"},
         "unet_ms_per_step_per_image": stage.get("sampler_ms", 0.0) / a.plms_steps / B,
         "stage_ms_per_batch": stage,
+        # reference-FLOP normalisation: what the reference's modules would execute per image (FlopCounterMode) ...
         "e2e_mfma_frac": value / world * flop_per_image / (MFMA_PEAK_TFLOPS * 1e12),
     }
+    if prof:
+        # ... and the FLOP this implementation actually LAUNCHES per step (matrix-core classes of the profiled pass): less than the
+        # reference count because attn2's dead q/k/softmax and the shared guidance prefix are not evaluated (bit-identical, tested)
+        exe = sum(prof[k]["work"] for k in ("conv3x3_igemm", "gemm", "attention") if k in prof)
+        line["executed_tflop_per_step"] = exe / 1e12
+        line["e2e_mfma_frac_executed"] = exe / (elapsed / a.steps) / (MFMA_PEAK_TFLOPS * 1e12)
+    if world > 1:
+        line["per_rank_ms"] = {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": [round(x, 2) for x in per_rank_ms]}
+        line["startup"] = build_info
+    if b16:
+        line["batch16"] = b16
     if prof:
         MFMA = ("conv3x3_igemm", "gemm", "attention")
         tj, traffic_src = measured_traffic()

@@ -249,6 +249,15 @@ int pbe_plms_update(const void* eps_out, int32_t ld, int32_t dup, float cfg_scal
                     float* e_t, float* x_prev, float* pred_x0, int32_t B, int32_t HW,
                     pbe_stream_t stream);
 
+/* Stochastic sampler options reachable from the reference CLI (scripts/inference.py:164,342 --ddim_eta; plms.py:150-153 / ddim.py:178-181):
+ * pbe_axpy_f32          y += a * x : the sigma_t * noise * temperature term of a DDIM step with eta > 0 (ddim.py:236-238);
+ * pbe_qsample_blend_f32 out = (sqrt_ac x0 + sqrt_1m_ac noise) * mask + (1 - mask) * img : img_orig = q_sample(x0, ts) blended under `mask`
+ *                       (fp32 NCHW [B,C,HW]; mask [B,1,HW] or [B,C,HW]).  The noise tensors are the caller's (the reference draws them
+ *                       from the device RNG: not reproducible across devices, so parity uses injected noise). */
+int pbe_axpy_f32(float* y, float a, const float* x, int64_t n, pbe_stream_t stream);
+int pbe_qsample_blend_f32(const float* x0, const float* noise, const float* mask, const float* img, float sqrt_ac, float sqrt_1m_ac,
+                          float* out, int32_t B, int32_t C, int32_t HW, int32_t mask_channels, pbe_stream_t stream);
+
 /* pbe_posterior_sample — distributions.py:25-37 + latent_diffusion.py:262:
  * moments fp16 NHWC [B,HW,ld] (mean 0..3 | logvar 4..7), eps fp32 NCHW [B,4,HW] ->
  * z fp32 NCHW = scale * (mean + exp(0.5 clamp(logvar,-30,20)) * eps). */

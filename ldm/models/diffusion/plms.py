@@ -13,7 +13,10 @@ What differs from the reference loop (same arithmetic):
     the 16 cross-attention constants are computed once per run,
   * ``test_model_kwargs`` may use either key spelling (``inpaint_image``/``inpaint_mask`` from
     scripts/inference.py:320-332 or ``images_inpaint``/``images_mask`` from plms.py:221-222).
-Unsupported reference options (score_corrector, quantize_denoised, mask/x0 blending, eta != 0,
+  * ``mask`` / ``x0`` (plms.py:150-153: img = q_sample(x0, ts) * mask + (1 - mask) * img before every step) and ``timesteps=``
+    (plms.py:132-139: a prefix of the schedule) run as in the reference; the q_sample noise comes from ``self.noise_like``
+    (default: the torch device generator, like the reference's randn_like - tests inject it).
+Unsupported reference options (score_corrector, quantize_denoised, eta != 0 - the reference's PLMS asserts that too -,
 noise_dropout, ddim_use_original_steps) raise instead of being silently ignored.
 """
 import math
@@ -48,6 +51,7 @@ class PLMSSampler(object):
         self.use_graph = None               # None = decide per run (pbe_amd.graph.graphs_enabled); True / False force
         self._graphed = None
         self.share_guidance_prefix = True   # evaluate the context-independent prefix of a guidance pair once (UNetModel.forward_nhwc paired=True)
+        self.noise_like = lambda shape, device: torch.randn(shape, device=device)      # util.py:264-267 (q_sample / DDIM eta > 0 noise)
         self.require_gpu = True       # host-logic tests clear this and substitute the two element-wise kernels; the kernels themselves have no CPU path
 
     def register_buffer(self, name, attr):
@@ -77,13 +81,15 @@ class PLMSSampler(object):
             raise PbeError("PLMSSampler.sample: conditioning is required")
         if conditioning.shape[0] != batch_size:
             print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
-        if quantize_x0 or mask is not None or x0 is not None or score_corrector is not None or noise_dropout != 0.:
-            raise PbeError("PLMSSampler: quantize_x0 / mask+x0 / score_corrector / noise_dropout are not on the Paint-by-Example path")
+        if quantize_x0 or score_corrector is not None or noise_dropout != 0.:
+            raise PbeError("PLMSSampler: quantize_x0 / score_corrector / noise_dropout are not on the Paint-by-Example path")
+        if (mask is None) != (x0 is None):
+            raise PbeError("PLMSSampler: mask and x0 go together (plms.py:150-153)")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C, H, W = shape
         return self.plms_sampling(conditioning, (batch_size, C, H, W), callback=callback, img_callback=img_callback, x_T=x_T,
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
-                                  unconditional_conditioning=unconditional_conditioning, **kwargs)
+                                  unconditional_conditioning=unconditional_conditioning, mask=mask, x0=x0, **kwargs)
 
     # ---- one U-Net evaluation with guidance (plms.py:181-195) -----------------------------------
     def _eps(self, x, step, ctx, z_inp, msk, dup):
@@ -104,11 +110,22 @@ class PLMSSampler(object):
         w = list(weights) + [0.0] * (4 - len(weights))
         return w + [float(self.ddim_sqrt_one_minus_alphas[index]), 1.0 / math.sqrt(a_t), math.sqrt(a_prev), math.sqrt(1.0 - a_prev)]
 
+    def _schedule_subset(self, timesteps):
+        """plms.py:132-139 / ddim.py:151-155: `timesteps` = how many of the schedule's steps to run (a prefix of ddim_timesteps)."""
+        if timesteps is None:
+            return self.ddim_timesteps
+        n = self.ddim_timesteps.shape[0]
+        subset_end = int(min(timesteps / n, 1) * n) - 1
+        return self.ddim_timesteps[:subset_end]
+
+    def _blend_known(self, img, x0, mask, step):
+        """img_orig = q_sample(x0, ts); img = img_orig * mask + (1 - mask) * img (plms.py:150-153), one kernel."""
+        ac = float(self.model.alphas_cumprod[int(step)])
+        return ops.qsample_blend(x0, self.noise_like(tuple(x0.shape), x0.device).float(), mask, img, math.sqrt(ac), math.sqrt(1.0 - ac))
+
     @torch.no_grad()
     def plms_sampling(self, cond, shape, x_T=None, callback=None, timesteps=None, img_callback=None, log_every_t=100,
-                      unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
-        if timesteps is not None:
-            raise PbeError("PLMSSampler: explicit timesteps subsets are not supported")
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, mask=None, x0=None, **kwargs):
         device = self.model.betas.device
         if self.require_gpu and device.type != "cuda":
             raise PbeError("PLMSSampler: the model must live on an MI355X (model.to('cuda')); there is no CPU path")
@@ -129,13 +146,17 @@ class PLMSSampler(object):
         dup = 2 if guided else 1
         scale = float(unconditional_guidance_scale)
 
-        time_range = np.flip(self.ddim_timesteps)
+        time_range = np.flip(self._schedule_subset(timesteps))
         total = time_range.shape[0]
+        if mask is not None:
+            mask, x0 = mask.to(device=device, dtype=torch.float32), x0.to(device=device, dtype=torch.float32)
         inter = {"x_inter": [img], "pred_x0": [img]}
         old = []                                                      # newest last, at most 3 (plms.py:163-165)
         for i, step in enumerate(time_range):
             index = total - i - 1
             step_next = time_range[min(i + 1, total - 1)]
+            if mask is not None:
+                img = self._blend_known(img, x0, mask, step)
             eps = self._eps(img, step, ctx, z_inp, msk, dup)
             if len(old) == 0:
                 # pseudo improved Euler (plms.py:230-235): probe x_prev with e_t, re-evaluate at t_next, average

@@ -450,6 +450,70 @@ def gen_full_plms():
     save("full_plms", **out)
 
 
+def gen_sampler_options():
+    """Reference samplers with the options that draw noise inside the loop, noise injected (narrow U-Net): DDIM eta = 0.7 /
+    temperature 0.9, DDIM with mask + x0, PLMS with mask + x0 and timesteps = 8 of 12."""
+    from ldm.models.diffusion import ddim as ref_ddim_mod
+    UP = "model.diffusion_model."
+    cu = CASES.UNET_NARROW
+    unet = build_ref_unet(cu, UP)
+    sd = sd_of(unet, UP)
+    inp = CASES.sampler_option_inputs()
+    ac = O.schedule_buffers()["alphas_cumprod"]
+    model_fn = lambda a, b, cc_: O.unet_forward(sd, a, b, cc_, cu, UP)          # noqa: E731
+    kw = {"images_inpaint": inp["z_inpaint"], "images_mask": inp["mask_lat"]}
+    out = {}
+
+    class _Stub(_RefLatentModel):
+        def __init__(self, unet, noises):
+            super().__init__(unet)
+            self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)                        # ddpm.py:205-206
+            self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
+            self.it = iter(noises)
+
+        def q_sample(self, x_start, t, noise=None):                                           # ddpm.py:337-341 with the injected noise
+            n = next(self.it)
+            return (self.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1) * x_start + self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1) * n)
+
+    # (a) stochastic DDIM
+    it = iter(inp["noises"])
+    keep = ref_ddim_mod.noise_like
+    ref_ddim_mod.noise_like = lambda shape, device, repeat=False: next(it)
+    try:
+        lm = _RefLatentModel(unet)
+        za, _ = _CpuDDIM(lm).sample(S=10, batch_size=2, shape=[4, 16, 16], conditioning=inp["c"], verbose=False, unconditional_guidance_scale=5.0,
+                                    unconditional_conditioning=inp["uc"], eta=0.7, temperature=0.9, x_T=inp["x_T"].clone(), test_model_kwargs=kw,
+                                    disable_tqdm=True)
+    finally:
+        ref_ddim_mod.noise_like = keep
+    oa, _ = O.ddim_sample(model_fn, 10, inp["x_T"], inp["c"], inp["uc"], 5.0, inp["z_inpaint"], inp["mask_lat"], ac, eta=0.7,
+                          noises=inp["noises"], temperature=0.9)
+    close(oa, za, "DDIM eta=0.7 temperature=0.9, 10 steps", rtol=2e-3)
+    out["ddim_eta_latent"] = za
+    # (b) DDIM with mask / x0
+    lm = _Stub(unet, inp["noises"])
+    zb, _ = _CpuDDIM(lm).sample(S=10, batch_size=2, shape=[4, 16, 16], conditioning=inp["c"], verbose=False, unconditional_guidance_scale=5.0,
+                                unconditional_conditioning=inp["uc"], eta=0.0, x_T=inp["x_T"].clone(), test_model_kwargs=kw, disable_tqdm=True,
+                                mask=inp["blend_mask"], x0=inp["x0"])
+    ob, _ = O.ddim_sample(model_fn, 10, inp["x_T"], inp["c"], inp["uc"], 5.0, inp["z_inpaint"], inp["mask_lat"], ac,
+                          blend=(inp["blend_mask"], inp["x0"], inp["noises"]))
+    close(ob, zb, "DDIM mask + x0, 10 steps", rtol=2e-3)
+    out["ddim_blend_latent"] = zb
+    # (c) PLMS with mask / x0 and a schedule prefix
+    lm = _Stub(unet, inp["noises"])
+    smp = _CpuPLMS(lm)
+    smp.make_schedule(ddim_num_steps=12, ddim_eta=0.0, verbose=False)
+    zc, _ = smp.plms_sampling(inp["c"], (2, 4, 16, 16), x_T=inp["x_T"].clone(), timesteps=8, mask=inp["blend_mask"], x0=inp["x0"],
+                              unconditional_guidance_scale=5.0, unconditional_conditioning=inp["uc"], test_model_kwargs=kw)
+    oc, info = O.plms_sample(model_fn, 12, inp["x_T"], inp["c"], inp["uc"], 5.0, inp["z_inpaint"], inp["mask_lat"], ac, timesteps=8,
+                             blend=(inp["blend_mask"], inp["x0"], inp["noises"]))
+    close(oc, zc, "PLMS mask + x0, timesteps=8 of 12", rtol=2e-3)
+    out["plms_blend_subset_latent"] = zc
+    out["plms_blend_subset_calls"] = np.int64(info["calls"])
+    assert lm.calls == info["calls"], (lm.calls, info["calls"])
+    save("sampler_options", **out)
+
+
 def gen_full_plms50():
     """The HEADLINE trajectory at headline size: reference PLMSSampler + reference UNetModel at 320 channels,
     S = 50, guidance 5, one sample; x after steps 0 / 3 / 25 / 49 and the final latent.  ~51 CFG U-Net pairs on the CPU, twice
@@ -502,3 +566,5 @@ if __name__ == "__main__":
         gen_full_plms()
     if "full_plms50" in todo:
         gen_full_plms50()
+    if "sampler_options" in todo:
+        gen_sampler_options()

@@ -387,15 +387,31 @@ def _guided_eps(model: ModelFn, x9, t, c, uc, scale):
     return e_u + scale * (e_c - e_u)
 
 
+def schedule_subset(ddim_t: np.ndarray, timesteps: Optional[int]) -> np.ndarray:
+    """plms.py:132-139 / ddim.py:151-155: `timesteps` keeps a PREFIX of the schedule (subset_end = int(min(t / n, 1) n) - 1)."""
+    if timesteps is None:
+        return ddim_t
+    n = ddim_t.shape[0]
+    return ddim_t[:int(min(timesteps / n, 1) * n) - 1]
+
+
+def q_sample(x0: torch.Tensor, step: int, noise: torch.Tensor, alphas_cumprod: np.ndarray) -> torch.Tensor:
+    """ddpm.py:337-341 with the registered fp32 buffers sqrt_alphas_cumprod / sqrt_one_minus_alphas_cumprod (ddpm.py:205-206)."""
+    ac = np.float64(alphas_cumprod[int(step)])
+    return float(np.float32(np.sqrt(ac))) * x0 + float(np.float32(np.sqrt(1.0 - ac))) * noise
+
+
 def plms_sample(model: ModelFn, S: int, x_T: torch.Tensor, cond: torch.Tensor, uc: Optional[torch.Tensor],
                 scale: float, z_inpaint: torch.Tensor, mask: torch.Tensor, alphas_cumprod: np.ndarray,
-                record: Sequence[int] = ()) -> Tuple[torch.Tensor, Dict[str, object]]:
+                record: Sequence[int] = (), timesteps: Optional[int] = None, blend=None) -> Tuple[torch.Tensor, Dict[str, object]]:
     """plms.py:118-248 with eta = 0 (sigma = 0): returns (x_0 latent, info).
-    info['calls'] counts model invocations (S + 1), info['x'] holds x after the steps in `record`."""
+    info['calls'] counts model invocations (S + 1), info['x'] holds x after the steps in `record`.
+    blend = (mask, x0, [noise per step]): plms.py:150-153, img = q_sample(x0, ts) * mask + (1 - mask) * img before every step."""
     ddim_t = ddim_timesteps_uniform(S, alphas_cumprod.shape[0])
     _, a, a_prev = ddim_parameters(alphas_cumprod, ddim_t)
     sq1m = np.sqrt(1.0 - a)
-    time_range = np.flip(ddim_t)
+    time_range = np.flip(schedule_subset(ddim_t, timesteps))
+    S = time_range.shape[0]
     b = x_T.shape[0]
     x = x_T.float()
     calls = 0
@@ -415,6 +431,9 @@ def plms_sample(model: ModelFn, S: int, x_T: torch.Tensor, cond: torch.Tensor, u
     pred_x0 = x
     for i, step in enumerate(time_range):
         idx = S - i - 1
+        if blend is not None:
+            bm, bx0, bnoise = blend
+            x = q_sample(bx0, step, bnoise[i], alphas_cumprod) * bm + (1.0 - bm) * x
         e_t = eps_at(x, step)
         if len(old) == 0:                                           # plms.py:230-235
             x_prev, _ = step_to_prev(e_t, idx)
@@ -437,22 +456,32 @@ def plms_sample(model: ModelFn, S: int, x_T: torch.Tensor, cond: torch.Tensor, u
 
 def ddim_sample(model: ModelFn, S: int, x_T: torch.Tensor, cond: torch.Tensor, uc: Optional[torch.Tensor],
                 scale: float, z_inpaint: torch.Tensor, mask: torch.Tensor, alphas_cumprod: np.ndarray,
-                record: Sequence[int] = ()) -> Tuple[torch.Tensor, Dict[str, object]]:
-    """ddim.py:193-242 with eta = 0: one model call per step, x[:, :4] slice for pred_x0."""
+                record: Sequence[int] = (), eta: float = 0.0, noises=None, temperature: float = 1.0, timesteps: Optional[int] = None,
+                blend=None) -> Tuple[torch.Tensor, Dict[str, object]]:
+    """ddim.py:193-242: one model call per step, x[:, :4] slice for pred_x0.  eta > 0 (util.py:69 sigmas, ddim.py:234-238):
+    x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noises[i] * temperature.  blend as in plms_sample."""
     ddim_t = ddim_timesteps_uniform(S, alphas_cumprod.shape[0])
     _, a, a_prev = ddim_parameters(alphas_cumprod, ddim_t)
+    sig = eta * np.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
     sq1m = np.sqrt(1.0 - a)
     b = x_T.shape[0]
     x = x_T.float()
     kept: Dict[int, torch.Tensor] = {}
     calls = 0
-    for i, step in enumerate(np.flip(ddim_t)):
+    time_range = np.flip(schedule_subset(ddim_t, timesteps))
+    S = time_range.shape[0]
+    for i, step in enumerate(time_range):
         idx = S - i - 1
+        if blend is not None:
+            bm, bx0, bnoise = blend
+            x = q_sample(bx0, step, bnoise[i], alphas_cumprod) * bm + (1.0 - bm) * x
         tt = torch.full((b,), int(step), dtype=torch.int64)
         e = _guided_eps(model, torch.cat((x, z_inpaint, mask), dim=1), tt, cond, uc, scale)
         calls += 1
         pred_x0 = (x - float(sq1m[idx]) * e) / math.sqrt(float(a[idx]))
-        x = math.sqrt(float(a_prev[idx])) * pred_x0 + math.sqrt(1.0 - float(a_prev[idx])) * e
+        x = math.sqrt(float(a_prev[idx])) * pred_x0 + math.sqrt(1.0 - float(a_prev[idx]) - float(sig[idx]) ** 2) * e
+        if eta != 0.0:
+            x = x + float(sig[idx]) * noises[i] * temperature
         if i in record:
             kept[i] = x.clone()
     return x, {"calls": calls, "x": kept}

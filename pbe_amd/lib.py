@@ -66,6 +66,8 @@ SYMBOLS = {
     "pbe_nhwc_f16_to_nchw_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_plms_pack_input": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "pbe_plms_update": (c_i32, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_f32), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "pbe_axpy_f32": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "pbe_qsample_blend_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_posterior_sample": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "pbe_scale_latent_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "pbe_clip_patchify_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),

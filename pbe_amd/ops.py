@@ -564,6 +564,29 @@ def plms_update(eps_out: torch.Tensor, dup: int, cfg_scale: float, x: torch.Tens
     return x_prev, pred, e_t
 
 
+def axpy_(y: torch.Tensor, a: float, x: torch.Tensor) -> torch.Tensor:
+    """y += a * x in place (fp32): the sigma_t * noise term of a stochastic DDIM step (ddim.py:236-238)."""
+    _f(y, "axpy y"); _f(x, "axpy x")
+    if not y.is_contiguous() or not x.is_contiguous() or x.numel() != y.numel():
+        raise _l.PbeError("axpy_: contiguous tensors of equal size")
+    _l.check(_l.load().pbe_axpy_f32(_p(y), float(a), _p(x), y.numel(), _stream()), "pbe_axpy_f32")
+    return y
+
+
+def qsample_blend(x0: torch.Tensor, noise: torch.Tensor, mask: torch.Tensor, img: torch.Tensor, sqrt_ac: float, sqrt_1m_ac: float) -> torch.Tensor:
+    """img_orig = q_sample(x0, t); img_orig * mask + (1 - mask) * img (plms.py:150-153, ddim.py:178-181), fp32 NCHW."""
+    for t, n in ((x0, "x0"), (noise, "noise"), (mask, "mask"), (img, "img")):
+        _f(t, f"qsample_blend {n}")
+    x0, noise, mask, img = x0.contiguous(), noise.contiguous(), mask.contiguous(), img.contiguous()
+    B, Cc, H, W = img.shape
+    if x0.shape != img.shape or noise.shape != img.shape or mask.shape[0] != B or mask.shape[1] not in (1, Cc) or tuple(mask.shape[2:]) != (H, W):
+        raise _l.PbeError("qsample_blend: x0 / noise must match img, mask [B, 1 or C, H, W]")
+    out = torch.empty_like(img)
+    _l.check(_l.load().pbe_qsample_blend_f32(_p(x0), _p(noise), _p(mask), _p(img), float(sqrt_ac), float(sqrt_1m_ac), _p(out), B, Cc, H * W,
+                                             mask.shape[1], _stream()), "pbe_qsample_blend_f32")
+    return out
+
+
 def posterior_sample(moments: torch.Tensor, eps: torch.Tensor, scale: float) -> torch.Tensor:
     _h(moments, "posterior moments"); _f(eps, "posterior eps")
     B, H, W, ld = moments.shape

@@ -68,6 +68,27 @@ def broadcast_weights_(module: torch.nn.Module, src: int = 0, bucket_bytes: int 
     return {"bytes": float(total), "messages": float(msgs)}
 
 
+@torch.no_grad()
+def weights_checksum(module: torch.nn.Module) -> bool:
+    """True when every rank holds the same parameters / buffers: (sum, sum of |x|) over all floating tensors in fp64, MAX- and
+    MIN-reduced - equal on all ranks iff both reductions agree with the local value."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    dev = next(module.parameters()).device
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_floating_point():
+            d = t.data.double()
+            acc[0] += d.sum()
+            acc[1] += d.abs().sum()
+    if dist.get_backend() != "nccl":
+        acc = acc.cpu()
+    hi, lo = acc.clone(), acc.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
+
+
 def gather_images(images_u8: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
     """[b,3,H,W] uint8 per rank -> [W*b,3,H,W] on `dst` (rank-major), None elsewhere."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -92,3 +92,21 @@ def full_plms50_inputs():
     m[:, :, 14:50, 18:46] = 0.0
     return {"x_T": torch.randn(1, 4, 64, 64, generator=g), "z_inpaint": torch.randn(1, 4, 64, 64, generator=g) * 0.8, "mask_lat": m,
             "c": torch.randn(1, 1, 768, generator=g), "uc": torch.randn(1, 1, 768, generator=g), "steps": 50, "scale": 5.0}
+
+
+def sampler_option_inputs():
+    """Inputs of tests/golden/sampler_options.npz (narrow U-Net, 16x16 latents, 2 samples): the reference sampler options that draw
+    noise inside the loop - DDIM eta > 0 (ddim.py:226-238), mask / x0 blending through q_sample (plms.py:150-153, ddim.py:178-181) - and the
+    timesteps= prefix (plms.py:132-139), with the noise INJECTED (the reference draws it from the device RNG)."""
+    d = narrow_inputs()
+    g = torch.Generator().manual_seed(9091)
+    out = {"x_T": d["x_T"], "c": torch.randn(2, 1, 768, generator=g), "uc": torch.randn(2, 1, 768, generator=g),
+           "z_inpaint": torch.randn(2, 4, 16, 16, generator=g) * 0.8, "x0": torch.randn(2, 4, 16, 16, generator=g)}
+    m = torch.ones(2, 1, 16, 16)
+    m[:, :, 4:12, 3:11] = 0.0
+    out["mask_lat"] = m
+    bm = torch.zeros(2, 1, 16, 16)
+    bm[:, :, :, :6] = 1.0                                   # keep the known x0 on the left third
+    out["blend_mask"] = bm
+    out["noises"] = [torch.randn(2, 4, 16, 16, generator=g) for _ in range(12)]
+    return out

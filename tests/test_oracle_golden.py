@@ -110,6 +110,24 @@ def test_narrow_plms_and_ddim(gold, narrow_sd):
         _close(zd, g["ddim_latent"], rtol=2e-3, what="DDIM latent")
 
 
+def test_sampler_options_against_reference(golden_dir, narrow_sd):
+    """The reference samplers' noise-drawing options (DDIM eta > 0 ddim.py:226-238; mask / x0 blending plms.py:150-153, ddim.py:178-181;
+    timesteps= prefix plms.py:132-139) run by the REFERENCE with injected noise (tests/golden/sampler_options.npz) against the oracle."""
+    g = np.load(os.path.join(golden_dir, "sampler_options.npz"))
+    inp = cases.sampler_option_inputs()
+    ac = O.schedule_buffers()["alphas_cumprod"]
+    model = lambda a, b, cc: O.unet_forward(narrow_sd, a, b, cc, cases.UNET_NARROW, "model.diffusion_model.")      # noqa: E731
+    args = (inp["x_T"], inp["c"], inp["uc"], 5.0, inp["z_inpaint"], inp["mask_lat"], ac)
+    with torch.no_grad():
+        za, _ = O.ddim_sample(model, 10, *args, eta=0.7, noises=inp["noises"], temperature=0.9)
+        _close(za, g["ddim_eta_latent"], rtol=2e-3, what="DDIM eta 0.7")
+        zb, _ = O.ddim_sample(model, 10, *args, blend=(inp["blend_mask"], inp["x0"], inp["noises"]))
+        _close(zb, g["ddim_blend_latent"], rtol=2e-3, what="DDIM mask + x0")
+        zc, info = O.plms_sample(model, 12, *args, timesteps=8, blend=(inp["blend_mask"], inp["x0"], inp["noises"]))
+        assert info["calls"] == int(g["plms_blend_subset_calls"]) == 8            # 7 steps of the 12-step schedule + the extra first-step call
+        _close(zc, g["plms_blend_subset_latent"], rtol=2e-3, what="PLMS mask + x0, schedule prefix")
+
+
 def test_plms_call_count_100_steps():
     """S = 100 -> 101 model evaluations (SURVEY.md §8c known answer), counted with a fake model."""
     n = {"c": 0}

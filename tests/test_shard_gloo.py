@@ -39,6 +39,12 @@ def _worker(rank, world, port, q):
             objs = [ref]
         dist.broadcast_object_list(objs, src=0)
         same = all(torch.equal(got[k], objs[0][k]) for k in got)
+        same = same and shard.weights_checksum(mod)                     # after the broadcast every rank holds the same weights ...
+        with torch.no_grad():
+            mod[1].weight[0, 0] += float(rank)                          # ... and a single differing element on one rank is noticed
+        same = same and not shard.weights_checksum(mod)
+        with torch.no_grad():
+            mod[1].weight[0, 0] -= float(rank)
         # the product's partition (pbe_amd.testbench.rank_batches): 11 items, batch 2 -> 5 full batches dealt round-robin, remainder dropped
         from pbe_amd.testbench import rank_batches
         mine = rank_batches(11, 2, rank, world)
@@ -136,7 +142,9 @@ def test_bench_self_launch_two_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out == {"rehearsal": True, "n_gpus": 2, "rank_sum": 3.0, "steps": 2, "warmup": 1}
+    # per_rank_ms: every rank's own time travels to rank 0 (min / max / all), so a scaling loss can be attributed to one slow device
+    assert out == {"rehearsal": True, "n_gpus": 2, "rank_sum": 3.0, "steps": 2, "warmup": 1,
+                   "per_rank_ms": {"min": 10.0, "max": 20.0, "all": [10.0, 20.0]}}
 
 
 @pytest.mark.timeout(300)
