@@ -1,22 +1,15 @@
-// Extended-epilogue (EX) dense tiles of the implicit-GEMM kernel (igemm_kernel.h): the transformer block's GEMM chain.
+// Extended-epilogue GEMMs (the transformer block's chain): plan, then the instantiation that carries exactly the requested features.
 #include "igemm_kernel.h"
 
-// extended epilogue (LayerNorm fold / row statistics / column-range alpha / V^T tiles): the EX instantiations, never split-K
+// (LayerNorm fold / row statistics / column-range alpha / V^T tiles; never split-K)
 void pbe_dispatch_ex(IGemmP p, int batch, hipStream_t s, int want_cfg) {
     p.ws = nullptr;
     const Plan pl = plan_igemm(p, batch, 0, want_cfg, 0);
     p.splits = 1;
-    switch (pl.cfg) {
-        case 3: launch_cfg<128, 128, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
-        case 4: launch_cfg<128, 64, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
-        case 5: launch_cfg<64, 128, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
-        case 8: launch_cfg<128, 320, 2, 4, 2, 0, 0, false, false, true>(p, batch, s); break;
-        case 9: launch_cfg<128, 160, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
-        case 15: launch_cfg<128, 128, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
-        case 16: launch_cfg<128, 64, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
-        case 17: launch_cfg<64, 64, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
-        case 18: launch_cfg<128, 160, 2, 2, 4, 0, 0, false, false, true>(p, batch, s); break;
-        default: launch_cfg<64, 64, 2, 2, 2, 0, 0, false, false, true>(p, batch, s); break;
-    }
+    // (the ln / qkv instantiations fold unconditionally: they are only ever launched with ln_stat)
+    const bool ln = p.ln_stat != nullptr, st = p.rstat != nullptr, vt = p.vt != nullptr || p.alpha_cols > 0;
+    if (ln && !st && !vt) pbe_launch_ex_ln(pl.cfg, p, batch, s);
+    else if (st && !ln && !vt) pbe_launch_ex_st(pl.cfg, p, batch, s);
+    else if (ln && vt && !st) pbe_launch_ex_qkv(pl.cfg, p, batch, s);
+    else pbe_launch_ex_all(pl.cfg, p, batch, s);
 }
-

@@ -110,6 +110,9 @@ struct IGemmP {
 
 static __device__ __attribute__((aligned(16))) unsigned int g_pbe_zero16[4] = {0u, 0u, 0u, 0u};   // (one copy per translation unit)
 
+#define EX_LN 1
+#define EX_ST 2
+#define EX_VT 4
 #define PBE_GLDS16(gsrc, ldst)                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),         \
                                      (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
@@ -137,15 +140,19 @@ __device__ __forceinline__ f32x4 mfma_pair_f8(const h16x8& w, const h16x8& a, f3
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[1], av[1], acc, 0, 0, 0);
 }
 
-// (the 4-wave tiles of the extended epilogue live two workgroups per CU - two waves per SIMD, 256 registers each: declared, so the
-//  allocator does not take the 260+ it would like for the 128x160 tile and halve the occupancy)
-template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false, bool EX = false>
+// (the 4-wave tiles live two workgroups per CU - two waves per SIMD, 256 registers each.  The V^T form of the 128x160 tile would take 268
+//  and halve the occupancy: its bound is declared; the LayerNorm-only (252) and statistics-only (228) forms fit unconstrained and
+//  keep their natural allocation - capped to 192 registers the GEGLU projection ran 11 % slower)
+template <int BM, int BN, int NWM, int NWN, int MODE, int S, int HPA = 0, bool PP = false, bool F8 = false, int EX = 0>
 #ifndef PBE_EX_MINWAVES
 #define PBE_EX_MINWAVES 2
 #endif
-__global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2) ? PBE_EX_MINWAVES : 1) igemm_kernel(const IGemmP p, int tiles_n) {
-    // EX (MODE 0, fp16 operands, one-pass epilogue tiles): the extended epilogue - LayerNorm folded in, row statistics out, column-range
-    // alpha, transposed V^T tiles (see IGemmP).  A separate instantiation so that the conv tiles' code and registers do not change.
+__global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 4 && S == 2) ? PBE_EX_MINWAVES : 1) igemm_kernel(const IGemmP p, int tiles_n) {
+    // EX (MODE 0, fp16 operands, one-pass epilogue tiles): the extended epilogue, a bit mask of what THIS instantiation carries -
+    // EX_LN LayerNorm folded in, EX_ST row statistics out, EX_VT column-range alpha + transposed V^T tiles (see IGemmP).  Separate
+    // instantiations per combination in use (GEGLU: EX_LN; proj_in / to_out: EX_ST; q|k|v^T: EX_LN | EX_VT): a kernel's registers are
+    // the maximum over its paths, and the all-in-one form ran the GEGLU projection 11 % slower than the plain tile (tools/gemm_ex_ab.py).
+    constexpr bool EXL = (EX & 1) != 0, EXS = (EX & 2) != 0, EXV = (EX & 4) != 0;
     // F8 (MODE 0 only): A and W hold OCP e4m3 bytes, a k-tile row of 128 B is 128 k-values; v_mfma_f32_16x16x32_fp8_fp8 runs at
     // the fp16 MFMA's rate, the gain is half the bytes through the fill path that bounds these GEMMs.  The epilogue multiplies
     // by the per-row scale of A and the per-row scale of W (per output column) before bias / activation / residual.
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
     constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES : S * STAGE;
     static_assert(S >= 2 && S <= 4 && PA % NW == 0 && (PW % NW == 0 || MODE == 2) && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
     static_assert(MODE != 2 || (HPA % 8 == 0 && HPA >= BM), "halo image must hold the tile");
-    static_assert(!EX || (MODE == 0 && !F8), "extended epilogue: dense fp16 tiles only");
+    static_assert(EX == 0 || (MODE == 0 && !F8), "extended epilogue: dense fp16 tiles only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
                 else { const int c = idx - BM; if (p.sw && n0 + c < p.N) v = p.sw[bz * p.ssw + n0 + c]; scw[c] = v; }
             }
         }
-        if constexpr (EX) {
+        if constexpr (EXL) {
             if (p.ln_stat) {
                 for (int idx = tid; idx < BM + BN; idx += NT) {
                     if (idx < BM) {
@@ -831,18 +838,18 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
     // activation stays a uniform run-time branch per quad.
     constexpr bool ARMS = TM * TN * 4 <= 96;
     constexpr int CLDT = GR + 8;                      // EX: row stride of the transposed C tile (V^T tiles)
-    static_assert(!EX || (ONE_PASS && (size_t)BN * CLDT * 2 <= (size_t)S * STAGE), "extended epilogue: whole C tile (either orientation) in the ring's LDS");
-    const bool vtile = EX && p.vt && n0 >= p.vt_col0;     // uniform: this tile's columns belong to the transposed output
-    auto stage = [&](int g, auto FAST, auto ACT) {
-        constexpr bool F = decltype(FAST)::value;
+    static_assert(EX == 0 || (ONE_PASS && (size_t)BN * CLDT * 2 <= (size_t)S * STAGE), "extended epilogue: whole C tile (either orientation) in the ring's LDS");
+    const bool vtile = EXV && p.vt && n0 >= p.vt_col0;     // uniform: this tile's columns belong to the transposed output
+    auto stage = [&](int g, auto FAST, auto ACT, auto VTT) {
+        constexpr bool F = decltype(FAST)::value, VT = decltype(VTT)::value;
         const int A = decltype(ACT)::value >= 0 ? decltype(ACT)::value : p.act;
         // alpha is re-materialised opaquely per pass: as a plain loop invariant, acc * alpha is hoisted out of the pass loop
         // into a second full set of accumulator registers and the 256-row tiles spill (measured: 30 us of epilogue per tile).
         float al = p.alpha;
         asm volatile("" : "+s"(al));
-        float ln_rs[EX ? TM : 1], ln_nm[EX ? TM : 1];      // EX + LayerNorm fold: this lane's rows' rstd and -mean rstd (LDS, read once)
-        if constexpr (EX) {
-            if (p.ln_stat) {
+        float ln_rs[EXL ? TM : 1], ln_nm[EXL ? TM : 1];    // LayerNorm fold: this lane's rows' rstd and -mean rstd (LDS, read once)
+        if constexpr (EXL) {
+            if (EX != 7 || p.ln_stat) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int ml = (ONE_PASS ? wm * WM : 0) + j * 16 + fr;
@@ -855,9 +862,9 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
             const int nl = wn * WN + i * 16 + fq * 4;
             const int n = n0 + nl;
             float ali = al, c1a[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EX) {
-                ali = (p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : al;
-                if (p.ln_stat) {
+            if constexpr (EXV) ali = (p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : al;
+            if constexpr (EXL) {
+                if (EX != 7 || p.ln_stat) {
                     const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnc + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) c1a[r] = ali * c1[r];
@@ -897,16 +904,21 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
                     const f32x4 sn = *reinterpret_cast<const f32x4*>(scw + nl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], sm * sn[r], add[r]);
-                } else if constexpr (EX) {
-                    if (p.ln_stat) {                         // LN(x) W^T = rstd (x W'^T - mean colsum(W')) with W' = W gamma (bias holds W beta + b)
+                } else if constexpr (EX != 0) {
+                    // NO run-time branch inside the unrolled body: a uniform branch per quad splits it into 40 basic blocks and the
+                    // GELU chains (rcp -> 4 fma -> exp) of different quads can no longer be interleaved (the GEGLU projection ran 12 % slower).
+                    // The LayerNorm-only / q|k|v forms therefore ALWAYS fold (their dispatch guarantees ln_stat), the V^T orientation is a
+                    // compile-time argument of stage(); only the catch-all form (EX = 7) decides at run time.
+                    if constexpr (EXL && EX != 7) {          // LN(x) W^T = rstd (x W'^T - mean colsum(W')) with W' = W gamma (bias holds W beta + b)
                         const float ars = ali * ln_rs[j];    //   alpha (rstd acc - mean rstd colsum) + bias  =  acc (alpha rstd) + ((-mean rstd) (alpha colsum) + bias)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ars, __builtin_fmaf(ln_nm[j], c1a[r], add[r]));
                     } else {
+                        const float ars = (EXL && p.ln_stat) ? ali * ln_rs[j] : ali, nmj = (EXL && p.ln_stat) ? ln_nm[j] : 0.f;      // (c1a = 0 without ln_stat)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ali, add[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ars, __builtin_fmaf(nmj, c1a[r], add[r]));
                     }
-                    if (vtile) {                             // V^T tile: the C tile goes to LDS transposed, [column][row]
+                    if constexpr (VT) {                      // V^T tile: the C tile goes to LDS transposed, [column][row]
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sC[(nl + r) * CLDT + ml] = (h16)v[r];
                         continue;
@@ -947,7 +959,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
         // (tiles whose accumulators stay live across the passes - NG > 1 - have no registers for a deep batch)
         constexpr int UB = !ONE_PASS ? (IT % 2 == 0 ? 2 : 1) : (IT % 5 == 0 ? 5 : (IT % 4 == 0 ? 4 : (IT % 3 == 0 ? 3 : (IT % 2 == 0 ? 2 : 1))));
         const int Nout = gg ? p.N >> 1 : p.N, nb = gg ? n0 >> 1 : n0;
-        if constexpr (EX && !gg) {
+        if constexpr (EXV && !gg) {
             if (vtile) {
                 // transposed tile: LDS row = output channel, 16-byte chunks of 8 consecutive tokens -> vt[b][channel][token] rows
                 constexpr int tpr = GR / 8;
@@ -960,6 +972,8 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
                 }
                 return;
             }
+        }
+        if constexpr (EXS && !gg) {
             if (p.rstat) {
                 // Row statistics for the LayerNorm that reads this output: 8 lanes per row (full 128-byte lines per row and
                 // instruction), each lane sums the STORED fp16 values of its chunks, three xor-shuffles finish the row -
@@ -1054,16 +1068,19 @@ __global__ void __launch_bounds__(NWM* NWN * 64, (EX && NWM * NWN == 4 && S == 2
         __syncthreads();                              // ring reads (g == 0) / previous group's copy-out done
         if (ONE_PASS || wm == g) {
             auto run = [&](auto FAST) {
+                if constexpr (EXV) {
+                    if (vtile) { stage(g, FAST, std::integral_constant<int, 0>{}, std::true_type{}); return; }      // V^T tiles: no activation
+                }
                 if constexpr (ARMS) {
                     switch (p.act) {
-                        case 1: stage(g, FAST, std::integral_constant<int, 1>{}); break;
-                        case 2: stage(g, FAST, std::integral_constant<int, 2>{}); break;
-                        case 3: stage(g, FAST, std::integral_constant<int, 3>{}); break;
-                        case PBE_ACT_GEGLU: stage(g, FAST, std::integral_constant<int, PBE_ACT_GEGLU>{}); break;
-                        default: stage(g, FAST, std::integral_constant<int, 0>{}); break;
+                        case 1: stage(g, FAST, std::integral_constant<int, 1>{}, std::false_type{}); break;
+                        case 2: stage(g, FAST, std::integral_constant<int, 2>{}, std::false_type{}); break;
+                        case 3: stage(g, FAST, std::integral_constant<int, 3>{}, std::false_type{}); break;
+                        case PBE_ACT_GEGLU: stage(g, FAST, std::integral_constant<int, PBE_ACT_GEGLU>{}, std::false_type{}); break;
+                        default: stage(g, FAST, std::integral_constant<int, 0>{}, std::false_type{}); break;
                     }
                 } else {
-                    stage(g, FAST, std::integral_constant<int, -1>{});
+                    stage(g, FAST, std::integral_constant<int, -1>{}, std::false_type{});
                 }
             };
             if (fast) run(std::true_type{});
@@ -1255,7 +1272,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
 extern int g_pbe_pingpong;      // pbe_tune(4, 0/1): ping-pong main loop of the halo-resident conv tiles
 extern int g_pbe_mfast;         // pbe_tune(5, 0/1): let a launch walk its tiles m fastest per XCD when that fetches fewer bytes
 
-template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false, bool EX = false>
+template <int BM, int BN, int NWM, int NWN, int S, int MODE, int HPA = 0, bool PP = false, bool F8 = false, int EX = 0>
 static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     // (ping-pong only where a wave's MFMA phase - (BM/NWM/16) x (BN/NWN/16) x 2 MFMAs - is as long as its read phase: measured
     //  25 % SLOWER on the 128x160 halo tile, whose 20 MFMAs cannot cover 14 fragment reads + 3 DMA issues)
@@ -1265,8 +1282,8 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
     constexpr size_t ring = MODE == 2 ? (size_t)2 * HPA * 128 + (size_t)S * BN * 128 : (size_t)S * (BM + BN) * 128;
     constexpr size_t c_bytes = (size_t)(BM / NWM) * (BN + 8) * 2;
     constexpr int SVR = (ring > c_bytes ? ring : c_bytes) + 4 * BN * sizeof(float) <= 160 * 1024 ? 4 : 3;                              // svec rows (samples per tile)
-    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + (EX ? 4 : SVR) * BN * sizeof(float) +     // + svec[SVR][BN]
-                           (F8 ? (BM + BN) * sizeof(float) : 0) + (EX ? (2 * BM + BN) * sizeof(float) : 0);                            // + operand scales / LayerNorm rows + colsum
+    constexpr size_t lds = (ring > c_bytes ? ring : c_bytes) + (MODE == 1 ? 9 * BM * sizeof(int) : 0) + (EX != 0 ? 4 : SVR) * BN * sizeof(float) +     // + svec[SVR][BN]
+                           (F8 ? (BM + BN) * sizeof(float) : 0) + (EX != 0 ? (2 * BM + BN) * sizeof(float) : 0);                            // + operand scales / LayerNorm rows + colsum
     p.sv_ok = !p.rowvec || p.group_rows % BM == 0 || (BM % p.group_rows == 0 && BM / p.group_rows <= SVR);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static std::atomic<uint64_t> attr_done{0};
@@ -1307,4 +1324,8 @@ void pbe_dispatch_dense(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int
 void pbe_dispatch_conv(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int want_cfg);      // MODE 1 gather tiles; forwards tiles 10-14 to
 void pbe_launch_halo(int cfg, IGemmP p, int batch, hipStream_t s);                              // MODE 2 halo-resident tiles
 void pbe_dispatch_f8(IGemmP p, int batch, hipStream_t s, int want_cfg);
-void pbe_dispatch_ex(IGemmP p, int batch, hipStream_t s, int want_cfg);
+void pbe_dispatch_ex(IGemmP p, int batch, hipStream_t s, int want_cfg);          // picks the feature combination: igemm_ex_{ln,st,qkv,all}.hip
+void pbe_launch_ex_ln(int cfg, IGemmP p, int batch, hipStream_t s);
+void pbe_launch_ex_st(int cfg, IGemmP p, int batch, hipStream_t s);
+void pbe_launch_ex_qkv(int cfg, IGemmP p, int batch, hipStream_t s);
+void pbe_launch_ex_all(int cfg, IGemmP p, int batch, hipStream_t s);

@@ -51,6 +51,9 @@ def main():
                 def plain():
                     flush.zero_()
                     return ops.gemm(x, wg, bg, act=ops.ACT_GEGLU)
+                def ex_plain():                          # the EX instantiation without the fold (alpha_cols = N, alpha = 1: arithmetic unchanged)
+                    flush.zero_()
+                    return ops.gemm(x, wg, bg, act=ops.ACT_GEGLU, alpha_cols=8 * C)
                 def folded():
                     flush.zero_()
                     return ops.gemm(x, wg, bg, act=ops.ACT_GEGLU, ln=(st, c1, 1e-5))
@@ -60,7 +63,7 @@ def main():
                 def flush_only():
                     flush.zero_()
                 base = timeit(flush_only)
-                for name, fn in (("geglu plain", plain), ("geglu LN-folded", folded), ("layernorm", lnorm)):
+                for name, fn in (("geglu plain", plain), ("geglu EX no fold", ex_plain), ("geglu LN-folded", folded), ("layernorm", lnorm)):
                     res.setdefault((name, cfg), []).append(timeit(fn) - base)
         ops._FORCE_CFG = None
         for k in sorted(res):
