@@ -397,7 +397,7 @@ def main():
             if mf:
                 row["gflop_per_launch"] = v["work"] / v["launches"] / 1e9
             t = (tj or {}).get("classes", {}).get(k)
-            row["traffic"] = t["traffic_B_per_launch"] if t else None
+            row["traffic"] = (t["traffic_B_per_pass"] / v["launches"] if "traffic_B_per_pass" in t else t["traffic_B_per_launch"]) if t else None
             classes[k] = row
         dom = max((k for k in classes if k in MFMA), key=lambda k: classes[k]["ms"])           # the class with the most GPU time
         d = classes[dom]

@@ -458,7 +458,13 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     const bool two = g_pbe_attn_qw ? g_pbe_attn_qw == 2 : (blocks2 >= 512 && D <= 80);
     if (D <= 16) launch_attn<16, 1>(p, s);
     else if (D <= 32) launch_attn<32, 1>(p, s);
-    else if (D == 40 && g_pbe_attn_mpad) { if (two) launch_attn<48, 2, 1, true>(p, s); else launch_attn<48, 1, 1, true>(p, s); }     // the U-Net's 64x64 / CFG heads
+    else if (D == 40 && g_pbe_attn_mpad) {                                                                                             // the U-Net's 64x64 / CFG heads
+        // (two K/V tiles per barrier where the grid covers the chip: 236 vs 240 us at 64x64, tools/attn_ab.py - the deeper prefetch alone is
+        //  worth 1.5 %: the kernel is bound by its MFMA / VALU streams, not by the DMA latency)
+        if (g_pbe_attn_qw == 2) launch_attn<48, 2, 1, true>(p, s);
+        else if (g_pbe_attn_qw == 1 || !two) launch_attn<48, 1, 1, true>(p, s);
+        else launch_attn<48, 2, 2, true>(p, s);
+    }
     else if (D <= 48) { if (g_pbe_attn_qw == 3) launch_attn<48, 2, 2>(p, s); else if (two) launch_attn<48, 2>(p, s); else launch_attn<48, 1>(p, s); }
     else if (D <= 64) { if (two) launch_attn<64, 2>(p, s); else launch_attn<64, 1>(p, s); }
     else if (D <= 80) { if (two) launch_attn<80, 2>(p, s); else launch_attn<80, 1>(p, s); }

@@ -38,7 +38,7 @@ def main():
         res = {}
         for rep in range(4):
             for mpad in ((0, 1) if D == 40 else (1,)):
-                for qw in (1, 2):
+                for qw in ((1, 2, 0) if D == 40 else (1, 2)):           # 0 = the dispatcher's choice (two K/V tiles per barrier at d = 40)
                     ops.tune(6, mpad); ops.tune(3, qw)
                     res.setdefault((mpad, qw), []).append(timeit(call))
         ops.tune(6, 1); ops.tune(3, 0)

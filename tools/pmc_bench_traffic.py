@@ -3,8 +3,8 @@
 the two implicit-GEMM kernel classes (3x3 conv: igemm_kernel<..., MODE = 1, S>; Linear / 1x1 GEMM: MODE = 0), as bench.py's
 `roofline.traffic` / `roofline.classes.*.traffic` want it, stamped with the library source hash and the tile-table hash.  Counters collected exactly as MI355X_MICROARCH.md §HBM prescribes:
 
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_bench/f -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_bench/w -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_bench/f -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-batch16
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_bench/w -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-batch16
     python tools/pmc_bench_traffic.py gpurun_out/pmc_bench/f gpurun_out/pmc_bench/w profiles/igemm_traffic.json
 
 (separate passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  Units and gfx950 corrections:
@@ -36,6 +36,9 @@ def per_kernel(d, counter):
     return tot, n
 
 
+PASSES = 2          # the profiled command runs the hot path twice (1 timed step + the stage-split pass)
+
+
 def main(fdir, wdir, outp):
     import hashlib
     import os
@@ -51,20 +54,30 @@ def main(fdir, wdir, outp):
         args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
         return args[4] if len(args) >= 5 else None
     classes = {}
-    for cname, modes, label in (("conv3x3_igemm", ("1", "2"), "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)"),
-                                ("gemm", ("0",), "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)")):
-        ks = [k for k in ft if mode_of(k) in modes]
+    # every class of bench.py's roofline.classes: the two igemm classes by MODE, the others by kernel name (all of them move 16 B per lane:
+    # LDS-DMA pieces, h16x8 / f32x4 loads and stores - the access shape the guide's FETCH_SIZE x 2 correction is calibrated for)
+    sel = (("conv3x3_igemm", lambda k: mode_of(k) in ("1", "2"), "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)"),
+           ("gemm", lambda k: mode_of(k) == "0", "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)"),
+           ("attention", lambda k: k.startswith("attn_kernel<"), "attn_kernel<*> (fused self-attention)"),
+           ("groupnorm", lambda k: k.startswith(("gn_stats_kernel", "gn_apply_kernel", "gn_small_kernel")), "gn_stats + gn_apply, gn_small"),
+           ("layernorm", lambda k: k.startswith(("layernorm_kernel<", "layernorm_f8_kernel<", "row_stats_kernel<")), "layernorm / row statistics kernels"),
+           ("splitk_reduce", lambda k: k.startswith("splitk_reduce_kernel"), "splitk_reduce_kernel"))
+    for cname, pred, label in sel:
+        ks = [k for k in ft if pred(k)]
+        if not ks:
+            continue
         launches = sum(fn[k] for k in ks)
         assert launches and launches == sum(wn[k] for k in ks), (cname, launches, sum(wn[k] for k in ks))
         rd = sum(ft[k] for k in ks) * 1024 * 2
         wr = sum(wt[k] for k in ks) * 1024
         classes[cname] = {"kernel": label, "launches": launches, "read_B_per_launch": rd / launches, "write_B_per_launch": wr / launches,
                           "traffic_B_per_launch": (rd + wr) / launches,
+                          "traffic_B_per_pass": (rd + wr) / PASSES,          # bench.py divides by ITS launch count (a GroupNorm call = 2 dispatches)
                           "per_tile_config": {k: {"launches": fn[k], "read_B_per_launch": ft[k] * 2048 / fn[k], "write_B_per_launch": wt[k] * 1024 / max(1, wn[k])}
                                               for k in sorted(ks)}}
     with open(os.path.join(root, "pbe_amd", "tuned_mi355x.json"), "rb") as f:
         table = hashlib.sha256(f.read()).hexdigest()[:16]
-    out = {"command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile (2 passes of the hot path)", "source_hash": lib.source_hash(), "tuned_table_sha": table,
+    out = {"command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-batch16 (2 passes of the hot path)", "passes": PASSES, "source_hash": lib.source_hash(), "tuned_table_sha": table,
            "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950: 64 B tallied per 128-B request); WRITE_SIZE KiB x 1024", "classes": classes}
     with open(outp, "w") as f:
         json.dump(out, f, indent=1)
