@@ -207,11 +207,12 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const h16* X, const h16* 
     }
 }
 
+int g_pbe_gn_rows = 16;      // pbe_tune(7, n): rows per thread of the two-pass GroupNorm kernels (developer knob)
 static void gn_geometry(int HW, int C, int* nchunks, int* rpb, int* TX, int* TY) {
     const int C8 = C / 8;
     *TX = C8 < 256 ? C8 : 256;
     *TY = 256 / *TX;
-    int rows = *TY * 16;                      // 16 rows per thread: four 4-deep load batches
+    int rows = *TY * g_pbe_gn_rows;           // 16 rows per thread: four 4-deep load batches
     if (rows < 32) rows = 32;
     int n = (HW + rows - 1) / rows;
     if (n > GN_MAX_CHUNKS) { n = GN_MAX_CHUNKS; rows = (HW + n - 1) / n; n = (HW + rows - 1) / rows; }

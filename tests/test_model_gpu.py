@@ -23,9 +23,10 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = 4e-3
+FWD_TOL = 4e-3            # one network forward (measured 1.4e-3 .. 2.0e-3; the reference's own autocast-fp16 drift is 2.06e-3)
+BLOCK_TOL = 2e-3          # one block against its reference module (measured 3.2e-4 .. 7.2e-4)
 SAMPLER_OPT_TOL = 6e-3     # 10-step narrow trajectories with injected noise (<= 3x measured)
-TRAJ50_TOL = 1e-2          # headline-size 50-step latent; set to <= 3x the measured value (profiles/r03_parity_report.txt)
+TRAJ50_TOL = 2.7e-3        # headline-size 50-step trajectory: measured 4.0e-4 (step 0), 9.3e-4, 8.5e-4, 8.6e-4 (final) - profiles/r03_parity_report.txt
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
 
 
@@ -72,31 +73,31 @@ def test_blocks_against_reference(dev, gold):
         for tag, cin, cout in (("res_skip", 64, 128), ("res_id", 128, 128)):
             m = ResBlock(cin, 256, 0.0, out_channels=cout)
             fill_module_(m, prefix=tag + ".")
-            check(f"ResBlock {cin}->{cout}", m.to(dev)(T(tag + "_x"), T(tag + "_emb")), g[tag + "_y"])
+            check(f"ResBlock {cin}->{cout}", m.to(dev)(T(tag + "_x"), T(tag + "_emb")), g[tag + "_y"], BLOCK_TOL)
         st = SpatialTransformer(64, 8, 8, depth=1, context_dim=768)
         fill_module_(st, prefix="st.")
-        check("SpatialTransformer C=64", st.to(dev)(T("st_x"), T("st_ctx")), g["st_y"])
+        check("SpatialTransformer C=64", st.to(dev)(T("st_x"), T("st_ctx")), g["st_y"], BLOCK_TOL)
         ff = FeedForward(64, glu=True)
         fill_module_(ff, prefix="ff.")
-        check("FeedForward GEGLU", ff.to(dev)(T("ff_x")), g["ff_y"])
+        check("FeedForward GEGLU", ff.to(dev)(T("ff_x")), g["ff_y"], BLOCK_TOL)
         dn, up = Downsample(64, True, out_channels=64), Upsample(64, True, out_channels=64)
         fill_module_(dn, prefix="dn."), fill_module_(up, prefix="up.")
-        check("Downsample", dn.to(dev)(T("st_x")), g["dn_y"])
-        check("Upsample", up.to(dev)(T("st_x")), g["up_y"])
+        check("Downsample", dn.to(dev)(T("st_x")), g["dn_y"], BLOCK_TOL)
+        check("Upsample", up.to(dev)(T("st_x")), g["up_y"], BLOCK_TOL)
         from pbe_amd import ops
         x_nhwc = lambda: ops.nchw_to_nhwc(T("st_x"))      # noqa: E731
         rb = vae.ResnetBlock(in_channels=64, out_channels=128, dropout=0.0, temb_channels=0)
         fill_module_(rb, prefix="vrb.")
-        check("VAE ResnetBlock", ops.nhwc_to_nchw(rb.to(dev).run(x_nhwc())), g["vrb_y"])
+        check("VAE ResnetBlock", ops.nhwc_to_nchw(rb.to(dev).run(x_nhwc())), g["vrb_y"], BLOCK_TOL)
         ab = vae.AttnBlock(64)
         fill_module_(ab, prefix="vab.")
-        check("VAE AttnBlock", ops.nhwc_to_nchw(ab.to(dev).run(x_nhwc())), g["vab_y"])
+        check("VAE AttnBlock", ops.nhwc_to_nchw(ab.to(dev).run(x_nhwc())), g["vab_y"], BLOCK_TOL)
         vd = vae.Downsample(64, True)
         fill_module_(vd, prefix="vdn.")
-        check("VAE Downsample (asym pad)", ops.nhwc_to_nchw(vd.to(dev).run(x_nhwc())), g["vdn_y"])
+        check("VAE Downsample (asym pad)", ops.nhwc_to_nchw(vd.to(dev).run(x_nhwc())), g["vdn_y"], BLOCK_TOL)
         tr, ln = Transformer(1, 128, 2, 1), LayerNorm(128)
         fill_module_(tr, prefix="mapper."), fill_module_(ln, prefix="final_ln.")
-        check("xf mapper + final_ln", ln.to(dev)(tr.to(dev)(T("map_z"))), g["map_y"])
+        check("xf mapper + final_ln", ln.to(dev)(tr.to(dev)(T("map_z"))), g["map_y"], BLOCK_TOL)
 
 
 # ---- narrow whole networks ------------------------------------------------------------------
@@ -172,12 +173,13 @@ def test_narrow_plms_trajectory(dev, gold, narrow):
         img = torch.clamp((narrow.decode_first_stage(z0.clone()) + 1.0) / 2.0, 0.0, 1.0)
     assert n == 51 == int(g["plms_calls_50"])                 # S + 1 U-Net evaluations (plms.py:230-235)
     assert len(inter["x_inter"]) == 51
-    for i, tol in zip(cases.PLMS_RECORD, (4e-3, 6e-3, 8e-3, 1e-2, 3e-2, 3e-2)):
+    # every tolerance below is <= 3x the value measured on MI355X (profiles/r03_parity_report.txt): 5.5e-4, 1.0e-3, 1.1e-3, 1.4e-3, 1.44e-3, 1.44e-3
+    for i, tol in zip(cases.PLMS_RECORD, (1.7e-3, 3e-3, 3.4e-3, 4e-3, 4.3e-3, 4.3e-3)):
         check(f"PLMS x after step {i}", inter["x_inter"][i + 1], g[f"plms_x_{i}"], tol)
-    check("PLMS final latent", z0, g["plms_latent"], 3e-2)
+    check("PLMS final latent", z0, g["plms_latent"], 4.3e-3)
     mad = (img.float().cpu() - torch.from_numpy(g["plms_image"])).abs().mean().item()
-    report("PLMS final image mean|d| (as rel_l2 column)", mad, 1e-2)
-    assert mad <= 1e-2
+    report("PLMS final image mean|d| (as rel_l2 column)", mad, 1.2e-3)                      # measured 4.1e-4
+    assert mad <= 1.2e-3
 
 
 def test_narrow_plms_key_spelling_and_ddim(dev, gold, narrow):
@@ -190,7 +192,30 @@ def test_narrow_plms_key_spelling_and_ddim(dev, gold, narrow):
         zd, _, n = _sample(narrow, dev, g, DDIMSampler, 20, "plms.py")
     assert torch.equal(a, b)
     assert n == 20
-    check("DDIM 20-step latent", zd, g["ddim_latent"], 3e-2)
+    check("DDIM 20-step latent", zd, g["ddim_latent"], 5e-3)                                # measured 1.7e-3
+
+
+def test_proj_out_pack_is_dropped_by_data_writes(dev):
+    """ddpm.HipLinear caches its fp16 pack keyed on (data_ptr, _version); writes through ``.data`` - what shard.broadcast_weights_ and
+    weights.fill_* do - do not move ``_version``, so those paths call ``invalidate_packs()`` on every module that has one: after it the
+    forward must use the NEW weight (round-2 advisor finding: a stale pack made the conditioning silently wrong)."""
+    from ldm.models.diffusion.ddpm import HipLinear
+    g = torch.Generator().manual_seed(21)
+    lin = HipLinear(128, 768).to(dev)
+    z = torch.randn(6, 1, 128, generator=g).to(dev)
+    with torch.no_grad():
+        y0 = lin(z).float()
+        w2, b2 = torch.randn(768, 128, generator=g).to(dev) * 0.1, torch.randn(768, generator=g).to(dev)
+        v0 = lin.weight._version
+        lin.weight.data.copy_(w2)
+        lin.bias.data.copy_(b2)
+        assert lin.weight._version == v0                                   # the hazard: the cache key cannot see this write
+        for m in lin.modules():                                            # what broadcast_weights_ / fill_latent_diffusion_ do after writing
+            if hasattr(m, "invalidate_packs"):
+                m.invalidate_packs()
+        y1 = lin(z).float()
+        ref = torch.nn.functional.linear(z.float(), w2, b2)
+    assert rel_l2(y1, ref.cpu()) < 2e-3 and rel_l2(y0, ref.cpu()) > 0.5
 
 
 def test_sampler_options_on_gpu(dev, golden_dir, narrow):
@@ -292,8 +317,8 @@ def test_full_pipeline_is_batch_independent(dev, full):
                           post_eps=inp["post_eps"][i:i + 1])
             check(f"batch independence: latent of sample {i} (B=4 vs B=1)", both["latent"][i:i + 1], one["latent"].float().cpu(), 8e-3)
             mad = (both["image"][i:i + 1] - one["image"]).abs().mean().item() * 255.0
-            report(f"batch independence: image of sample {i}, mean |d| in grey levels", mad, 1.0)
-            assert mad <= 1.0
+            report(f"batch independence: image of sample {i}, mean |d| in grey levels", mad, 0.5)   # measured 0.17
+            assert mad <= 0.5
         again = inpaint(full, inp["image"], inp["mask"], inp["ref"], steps=2, scale=5.0, x_T=inp["x_T"], post_eps=inp["post_eps"])
     assert torch.equal(both["latent"], again["latent"]) and torch.equal(both["image"], again["image"])       # run-to-run bit-identical
 
@@ -310,9 +335,9 @@ def test_full_plms_trajectory_against_reference(dev, golden_dir, full):
                                              x_T=inp["x_T"].to(dev), log_every_t=1,
                                              test_model_kwargs={"images_inpaint": inp["z_inpaint"].to(dev), "images_mask": inp["mask_lat"].to(dev)})
     assert len(inter["x_inter"]) == inp["steps"] + 1
-    for i, tol in zip(range(inp["steps"]), (4e-3, 6e-3, 8e-3, 1e-2)):
+    for i, tol in zip(range(inp["steps"]), (5.5e-3, 6.5e-3, 6.5e-3, 6.5e-3)):             # measured 1.9e-3, 2.2e-3, 2.2e-3, 2.2e-3
         check(f"v1-size PLMS x after step {i}", inter["x_inter"][i + 1], g[f"plms_x_{i}"], tol)
-    check("v1-size PLMS final latent (4 steps)", z0, g["plms_latent"], 1e-2)
+    check("v1-size PLMS final latent (4 steps)", z0, g["plms_latent"], 6.5e-3)
 
 
 def test_full_plms50_headline_trajectory_against_reference(dev, golden_dir, full):
@@ -450,8 +475,8 @@ def test_inference_cli_matches_oracle_pipeline(dev, golden_dir, tmp_path, exampl
     png = np.asarray(Image.open(os.path.join(str(tmp_path), "results", f"image_example_{example}_{seed}.png"))).astype(np.float32)
     exp = (255.0 * want["image"][0].permute(1, 2, 0).numpy()).astype(np.uint8).astype(np.float32)
     mad = float(np.abs(png - exp).mean())
-    report(f"CLI example_{example}: result PNG vs oracle, mean |d| in grey levels", mad, 1.0)
-    assert png.shape == (512, 512, 3) and mad <= 1.0
+    report(f"CLI example_{example}: result PNG vs oracle, mean |d| in grey levels", mad, 0.55)      # measured 0.16-0.18
+    assert png.shape == (512, 512, 3) and mad <= 0.55
     assert torch.equal(out, torch.from_numpy(t["image"]))
 
 
@@ -532,8 +557,8 @@ def test_pipeline_batch16_configs2_geometry(dev, full):
                           post_eps=inp["post_eps"][i:i + 1])
             check(f"configs[2] batch 16: latent of sample {i} vs alone", out["latent"][i:i + 1], one["latent"].float().cpu(), 8e-3)
             mad = (out["image"][i:i + 1] - one["image"]).abs().mean().item() * 255.0
-            report(f"configs[2] batch 16: image of sample {i}, mean |d| in grey levels", mad, 1.0)
-            assert mad <= 1.0
+            report(f"configs[2] batch 16: image of sample {i}, mean |d| in grey levels", mad, 0.5)  # measured 0.16
+            assert mad <= 0.5
         again = inpaint(full, inp["image"], inp["mask"], inp["ref"], steps=2, scale=5.0, x_T=inp["x_T"], post_eps=inp["post_eps"])
     assert torch.equal(out["latent"], again["latent"])
 
