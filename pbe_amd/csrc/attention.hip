@@ -27,6 +27,7 @@ struct AttnP {
     long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_rs, o_bs, o_rs;
     float scale_log2e;
     int q_pre;          // Q already multiplied by scale log2e (then scale_log2e == 1)
+    int nqb;            // query blocks per (batch, head): the grid is 1-D, nqb * B * H workgroups
 };
 
 #define PBE_GLDS16(gsrc, ldst)                                                                     \
@@ -56,6 +57,9 @@ __device__ __forceinline__ int attn_key_of_row(int r) { return (r & ~12) | ((r &
 // ones row of V^T, or the VALU row sum) see the same rounded P.  The rescale of O - and, in the MPAD form, the subtraction of m -
 // leave the per-tile path.
 #define ATTN_THR 8.0f
+#ifndef PBE_ATTN_PRIO
+#define PBE_ATTN_PRIO 0      // 1: s_setprio 1 around the MFMA phases (A/B build, tools/attn_ab.py with PBE_LIB_PATH)
+#endif
 
 template <int DP, int QW, int KH, bool MPAD = false>
 __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kernel(const AttnP p) {
@@ -80,8 +84,18 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * BQ + wave * 32 * QW + l31;          // sub-block i holds query q0 + 32 i
+    // Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share one; speed only, never correctness): the query blocks of ONE
+    // (batch, head) all stream the same K / V^T, so they are given ids of one residue mod 8 - that XCD's L2 then serves the 2nd .. 16th
+    // sweep.  With the plain (q block, head) grid every XCD fetched every head's K / V^T: 172 MB left L2 per launch against 43 MB
+    // algorithmic (profiles/r03 PMC passes).
+    int bh, qblk;
+    {
+        const int nq = p.nqb, nbh = p.B * p.H, lin = blockIdx.x;
+        if ((nbh & 7) == 0) { const int xcd = lin & 7, j = lin >> 3; qblk = j % nq; bh = (j / nq) * 8 + xcd; }
+        else { qblk = lin % nq; bh = lin / nq; }
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qblk * BQ + wave * 32 * QW + l31;          // sub-block i holds query q0 + 32 i
     const int D = p.D;
     const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const h16x8 one8 = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -363,12 +377,24 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         const int kv0 = t * KT;
 #pragma unroll
         for (int i = 0; i < QW; ++i) {
+#if PBE_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             qk(i, sk);
+#if PBE_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (PREFV && i == 0) load_v(sv);                 // in flight under the first softmax
             if (PREF && i == QW - 1 && next_k) load_k(next_k);   // the S MFMAs above were the last readers of kf
             __builtin_amdgcn_sched_barrier(0);
             softmax(i, kv0, t == 0);
+#if PBE_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             pv(i, sv);
+#if PBE_ATTN_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);              // sub-blocks stay sequential: their S / P registers are shared
         }
     };
@@ -425,8 +451,10 @@ static void launch_attn(const AttnP& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "attention tile exceeds the LDS");
     static std::atomic<uint64_t> attr_done{0};
     pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH, MPAD>), (int)lds);
-    dim3 grid(cdiv(p.Nq, 128 * QW), p.B * p.H);
-    hipLaunchKernelGGL((attn_kernel<DP, QW, KH, MPAD>), grid, dim3(256), lds, s, p);
+    AttnP q = p;
+    q.nqb = cdiv(p.Nq, 128 * QW);
+    dim3 grid((unsigned)(q.nqb * p.B * p.H));
+    hipLaunchKernelGGL((attn_kernel<DP, QW, KH, MPAD>), grid, dim3(256), lds, s, q);
 }
 
 int g_pbe_attn_qw = 0;       // pbe_tune(3, v): 0 = heuristic, 1 / 2 = force queries-per-wave factor
@@ -442,7 +470,7 @@ extern "C" int pbe_attention_f16(const pbe_attn_desc* d, pbe_stream_t stream) {
     PBE_REQUIRE(d->vt_rs >= (d->Nk + 7) / 8 * 8, "pbe_attention_f16: vt_rs must cover Nk rounded up to 8");
     PBE_REQUIRE(((uintptr_t)d->Q & 15) == 0 && ((uintptr_t)d->K & 15) == 0 && ((uintptr_t)d->VT & 15) == 0 && ((uintptr_t)d->O & 15) == 0,
                 "pbe_attention_f16: 16-byte alignment");
-    PBE_REQUIRE((long)d->B * d->H <= 65535, "pbe_attention_f16: B*H too large");
+    PBE_REQUIRE((long)d->B * d->H * ((d->Nq + 127) / 128) < (1L << 31), "pbe_attention_f16: too many workgroups");
     AttnP p;
     p.Q = (const h16*)d->Q; p.K = (const h16*)d->K; p.VT = (const h16*)d->VT; p.O = (h16*)d->O;
     p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk; p.D = d->D;
