@@ -304,7 +304,9 @@ int pbe_planes_to_u8_canvas(const float* src, void* canvas, int32_t H, int32_t W
  * key 1: force an implicit-GEMM tile config index (-1 = heuristic); key 2: allow split-K (0/1);
  * key 3: attention queries-per-wave factor (0 = heuristic, 1, 2); key 4: ping-pong main loop of the halo-resident conv tiles (0/1);
  * key 5: per-launch choice of the XCD tile order (m fastest where that fetches fewer bytes into the 8 L2s; 0 = always n fastest);
- * key 6: attention at d = 40 keeps the softmax reference maximum in the head-dim padding (0 = the multiply-add form).
+ * key 6: attention at d = 40 keeps the softmax reference maximum in the head-dim padding (0 = the multiply-add form);
+ * key 7: rows per thread of the two-pass GroupNorm kernels (default 16); key 8: extra dynamic LDS bytes per attention workgroup
+ *        (fewer resident workgroups per CU: occupancy experiments).
  */
 int pbe_tune(int32_t key, int32_t value);
 

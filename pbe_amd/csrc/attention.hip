@@ -445,12 +445,15 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     }
 }
 
+int g_pbe_attn_pad_lds = 0;  // pbe_tune(8, bytes): extra dynamic LDS per workgroup (fewer resident workgroups per CU: occupancy experiments only)
+
 template <int DP, int QW, int KH = 1, bool MPAD = false>
 static void launch_attn(const AttnP& p, hipStream_t s) {
-    constexpr size_t lds = 2 * KH * AttnTile<DP>::BUF;
-    static_assert(lds <= 160 * 1024, "attention tile exceeds the LDS");
+    constexpr size_t lds0 = 2 * KH * AttnTile<DP>::BUF;
+    static_assert(lds0 <= 160 * 1024, "attention tile exceeds the LDS");
+    const size_t lds = lds0 + (g_pbe_attn_pad_lds > 0 && lds0 + g_pbe_attn_pad_lds <= 160 * 1024 ? g_pbe_attn_pad_lds : 0);      // (occupancy experiments)
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH, MPAD>), (int)lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH, MPAD>), 160 * 1024);
     AttnP q = p;
     q.nqb = cdiv(p.Nq, 128 * QW);
     dim3 grid((unsigned)(q.nqb * p.B * p.H));

@@ -17,6 +17,7 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 3) { extern int g_pbe_attn_qw; g_pbe_attn_qw = value; return PBE_OK; }
     if (key == 4) { g_pbe_pingpong = value ? 1 : 0; return PBE_OK; }
     if (key == 5) { g_pbe_mfast = value ? 1 : 0; return PBE_OK; }
+    if (key == 8) { extern int g_pbe_attn_pad_lds; g_pbe_attn_pad_lds = value > 0 ? value : 0; return PBE_OK; }
     if (key == 7) { extern int g_pbe_gn_rows; g_pbe_gn_rows = value >= 1 ? value : 16; return PBE_OK; }
     if (key == 6) { extern int g_pbe_attn_mpad; g_pbe_attn_mpad = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
