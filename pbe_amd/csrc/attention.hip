@@ -28,6 +28,9 @@ struct AttnP {
     float scale_log2e;
     int q_pre;          // Q already multiplied by scale log2e (then scale_log2e == 1)
     int nqb;            // query blocks per (batch, head): the grid is 1-D, nqb * B * H workgroups
+#ifdef PBE_ATTN_STAMPS
+    unsigned long long* stamps;     // diagnostic build only (tools/attn_stamps.py): 4 words per workgroup, written by lane 0 of wave 0, read by nothing
+#endif
 };
 
 #define PBE_GLDS16(gsrc, ldst)                                                                     \
@@ -399,6 +402,9 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         }
     };
 
+#ifdef PBE_ATTN_STAMPS
+    if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (PREF) load_k(smem);
     for (int g = 0; g * KH < nt; ++g) {
         const int t0 = g * KH;
@@ -414,6 +420,9 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
         __builtin_amdgcn_sched_barrier(0);
     }
 
+#ifdef PBE_ATTN_STAMPS
+    if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // ---- normalise and store O[q, h*D + d] ----
 #pragma unroll
     for (int i = 0; i < QW; ++i) {
@@ -445,6 +454,10 @@ __global__ void __launch_bounds__(256, (QW == 2 && DP <= 48) ? 2 : 1) attn_kerne
     }
 }
 
+#ifdef PBE_ATTN_STAMPS
+unsigned long long* g_pbe_attn_stamps = nullptr;
+extern "C" int pbe_debug_set_attn_stamps(void* buf) { g_pbe_attn_stamps = (unsigned long long*)buf; return PBE_OK; }
+#endif
 int g_pbe_attn_pad_lds = 0;  // pbe_tune(8, bytes): extra dynamic LDS per workgroup (fewer resident workgroups per CU: occupancy experiments only)
 
 template <int DP, int QW, int KH = 1, bool MPAD = false>
@@ -456,6 +469,9 @@ static void launch_attn(const AttnP& p, hipStream_t s) {
     pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<DP, QW, KH, MPAD>), 160 * 1024);
     AttnP q = p;
     q.nqb = cdiv(p.Nq, 128 * QW);
+#ifdef PBE_ATTN_STAMPS
+    q.stamps = g_pbe_attn_stamps;
+#endif
     dim3 grid((unsigned)(q.nqb * p.B * p.H));
     hipLaunchKernelGGL((attn_kernel<DP, QW, KH, MPAD>), grid, dim3(256), lds, s, q);
 }
