@@ -146,7 +146,10 @@ typedef struct pbe_conv3x3_desc {
     const void* rowvec; /* fp16 [B, ldv]: per-(sample, channel) add (ResBlock emb, openaimodel.py:273) */
     const void* resid;  /* fp16 [B,Ho,Wo,Cout] */
     int32_t B, H, W, C1, C2, Cout;
-    int32_t stride, pad, upsample;
+    int32_t stride, pad, upsample; /* upsample: 0; 1 = nearest-2x fused in the gather (Wp as usual, 9 taps); 2 = the same operation in PHASE form: Wp holds
+                                      four weight sets [4][Cout][4*Cin] (phase (py, px) = output pixel parity; per phase the 3x3 taps that fall on one
+                                      source pixel are summed: pbe_amd.ops.pack_conv3x3_up_phases), four 2x2 convs on the source grid, 4/9 of the MACs;
+                                      pad 1, stride 1, no X2 / rowvec / resid */
     int32_t ldv;
     int32_t act;
     void* workspace;        /* optional split-K scratch, as in pbe_gemm_desc */

@@ -52,7 +52,8 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def _pack(self):
-        return SimpleNamespace(c=_pack_conv(self.conv))
+        # interpolate(nearest, 2x) + conv3x3 (model.py:44-53) as four 2x2 convs on the source grid (ops.pack_conv3x3_up_phases): 4 / 9 of the MACs
+        return SimpleNamespace(c=(ops.pack_conv3x3_up_phases(self.conv.weight), f32(self.conv.bias)))
 
     def run(self, x):
         return ops.conv3x3(x, self.pk().c[0], self.pk().c[1], upsample=True)

@@ -49,7 +49,8 @@ class Upsample(HipModule):
         self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
 
     def _pack(self):
-        return SimpleNamespace(w=ops.pack_conv3x3(self.conv.weight), b=f32(self.conv.bias))
+        # F.interpolate(nearest, 2x) + conv3x3 (openaimodel.py:109-119) as four 2x2 convs on the source grid: 4 / 9 of the MACs
+        return SimpleNamespace(w=ops.pack_conv3x3_up_phases(self.conv.weight), b=f32(self.conv.bias))
 
     def run(self, x):
         p = self.pk()

@@ -125,9 +125,11 @@ static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
     PBE_REQUIRE((d->C2 == 0) == (d->X2 == nullptr), "%s: X2 / C2 mismatch", who);
     PBE_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2", who);
     PBE_REQUIRE(d->pad == 0 || d->pad == 1, "%s: pad must be 0 or 1", who);
-    PBE_REQUIRE(d->upsample == 0 || (d->upsample == 1 && d->stride == 1), "%s: upsample only with stride 1", who);
+    PBE_REQUIRE(d->upsample == 0 || ((d->upsample == 1 || d->upsample == 2) && d->stride == 1), "%s: upsample only with stride 1", who);
+    PBE_REQUIRE(d->upsample != 2 || (d->pad == 1 && !d->resid && !d->rowvec), "%s: the phase form of the upsampling conv takes pad 1, no resid / rowvec", who);
     PBE_REQUIRE(al16(d->X) && al16(d->Wp) && al16(d->Y) && (!d->X2 || al16(d->X2)), "%s: 16-byte alignment", who);
-    const int Hv = d->H << d->upsample, Wv = d->W << d->upsample;
+    const bool phase = d->upsample == 2;          // nearest-2x + 3x3 as four 2x2 convs on the source grid (Wp = the four summed weight sets)
+    const int Hv = phase ? d->H : d->H << d->upsample, Wv = phase ? d->W : d->W << d->upsample;
     // output size: pad=1 -> floor((Hv + 2 - 3)/s) + 1 ; pad=0 is the VAE (0,1,0,1) pad: floor((Hv + 1 - 3)/s) + 1
     const int extra = d->pad ? 2 : 1;
     const int Ho = (Hv + extra - 3) / d->stride + 1, Wo = (Wv + extra - 3) / d->stride + 1;
@@ -137,13 +139,15 @@ static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
     memset(&p, 0, sizeof(p));
     p.A = (const h16*)d->X; p.A2 = (const h16*)d->X2; p.W = (const h16*)d->Wp; p.C = (h16*)d->Y;
     p.bias = d->bias; p.rowvec = (const h16*)d->rowvec; p.resid = (const h16*)d->resid;
-    p.M = (int)M; p.N = d->Cout; p.K = 9 * Cin; p.K1 = p.K;
+    p.M = (int)M; p.N = d->Cout; p.K = (phase ? 4 : 9) * Cin; p.K1 = p.K;
+    p.phase = phase ? 1 : 0;
+    if (phase) p.sW = (long)d->Cout * p.K;         // one weight set per output phase; blockIdx.y = phase
     p.ldw = p.K; p.ldc = d->Cout; p.ldr = d->Cout;
     p.ldv = d->ldv; p.group_rows = Ho * Wo;
     p.alpha = 1.f; p.act = d->act; p.bias_row = 0;
     p.vec = (d->Cout % 8 == 0) && (!d->resid || al16(d->resid));
     p.H = d->H; p.Wd = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Ho = Ho; p.Wo = Wo;
-    p.cstride = d->stride; p.pad = d->pad; p.ups = d->upsample;
+    p.cstride = d->stride; p.pad = d->pad; p.ups = phase ? 0 : d->upsample;
     p.cb = d->kblock > 0 ? d->kblock : 64;
     PBE_REQUIRE(p.cb % 64 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "%s: kblock=%d must be a multiple of 64 dividing C1=%d and C2=%d", who, p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
@@ -155,7 +159,7 @@ extern "C" int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream) {
     const int rc = fill_conv(d, p, "pbe_conv3x3_f16");
     if (rc != PBE_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    pbe_dispatch_conv(p, 1, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
+    pbe_dispatch_conv(p, p.phase ? 4 : 1, s, d->workspace ? d->workspace_bytes : 0, d->tile_cfg);
     PBE_LAUNCH_CHECK("pbe_conv3x3_f16");
     return PBE_OK;
 }
@@ -165,7 +169,7 @@ extern "C" int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t
     IGemmP p;
     const int rc = fill_conv(d, p, "pbe_conv3x3_plan");
     if (rc != PBE_OK) return rc;
-    report_plan(p, 1, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 1);
+    report_plan(p, p.phase ? 4 : 1, d->workspace ? d->workspace_bytes : 0, d->tile_cfg, out6, 1);
     *workspace_needed = out6[1] > 1 ? (size_t)out6[1] * p.M * p.N * sizeof(float) : 0;
     return PBE_OK;
 }

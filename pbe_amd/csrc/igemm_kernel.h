@@ -44,6 +44,7 @@ struct IGemmP {
     float alpha; int act; int bias_row; int vec;
     // conv gather
     int H, Wd, C1, C2, Ho, Wo, cstride, pad, ups, cb;   // cb = channel block of the K order (multiple of 64)
+    int phase;                                           // MODE 1: nearest-2x upsample + 3x3 conv as FOUR 2x2 convs on the source grid (see the tap table); blockIdx.y = output phase
     int th;                                              // MODE 2: image rows per tile (tile = th full rows, or whole images)
     // fp8 (OCP e4m3) operands: rows are bytes (the loader sees them as K/2 halfs); C = acc * sa[m] * sw[n] (* alpha) + ...
     const float* sa; const float* sw; long ssa, ssw;
@@ -239,12 +240,27 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
     const int sv_ns = (p.rowvec && p.group_rows < BM) ? BM / p.group_rows : 1;       // samples per tile (tile is sample-aligned when sv_ok)
     if (MODE == 1) {
         const int hw = p.Ho * p.Wo, Hv = p.H << p.ups, Wv = p.Wd << p.ups;
-        for (int row = tid; row < BM; row += NT) {            // one thread per tile row: one (b, oy, ox) decode, 9 taps
+        // Phase form (p.phase): a 3x3 conv over a nearest-2x upsampled image reads, for the output pixel (2y + py, 2x + px), only a 2x2
+        // block of SOURCE pixels - rows {y - 1 + py, y + py}, columns {x - 1 + px, x + px} - because the 9 taps fall on 4 distinct
+        // sources (py = 0: taps ky = 0 | 1, 2 -> rows y - 1 | y; py = 1: ky = 0, 1 | 2 -> y | y + 1).  The host sums the weights that
+        // share a source (4 weight sets of 4 taps): 4 / 9 of the MACs, rows = source pixels, blockIdx.y = phase, and the epilogue
+        // scatters row m = (b, y, x) to output pixel (2y + py, 2x + px).  Zero padding agrees: source row -1 <=> upsampled row -1 / -2.
+        const int py = p.phase ? (int)(blockIdx.y >> 1) : 0, px = p.phase ? (int)(blockIdx.y & 1) : 0;
+        for (int row = tid; row < BM; row += NT) {            // one thread per tile row: one (b, oy, ox) decode, 9 (or 4) taps
             const int m = m0 + row;
             const bool rok = m < p.M;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const int iy0 = oy * p.cstride - p.pad, ix0 = ox * p.cstride - p.pad;
+            if (p.phase) {
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const int iy = oy - 1 + py + (tp >> 1), ix = ox - 1 + px + (tp & 1);
+                    const bool ok = rok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                    tab[tp * BM + row] = ok ? (b * p.H + iy) * p.Wd + ix : -1;
+                }
+                continue;
+            }
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const int iy = iy0 + tp / 3, ix = ix0 + tp % 3;
@@ -270,9 +286,10 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
     }
     // conv K order: (channel block of cb, tap, channel): state of the NEXT k-tile to issue
     const int KB = MODE == 1 ? p.cb >> 6 : 1;        // k-tiles per (block, tap) visit
+    const int ntap = (MODE == 1 && p.phase) ? 4 : 9;
     int tap = 0, c0 = 0, kj = 0;
     if (MODE == 1 && kt0 > 0) {
-        const int per_blk = 9 * KB, cblk = kt0 / per_blk, r = kt0 - cblk * per_blk;
+        const int per_blk = ntap * KB, cblk = kt0 / per_blk, r = kt0 - cblk * per_blk;
         tap = r / KB; kj = r - tap * KB; c0 = cblk * p.cb + kj * 64;
     }
     // MODE 1: per piece the running source pointer and its advance per k-tile (a padding pixel keeps reading the zero block: advance 0)
@@ -335,7 +352,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
             c0 += 64;
             if (++kj == KB) {
                 kj = 0;
-                if (++tap == 9) tap = 0; else c0 -= p.cb;      // next tap of the same block, or first tap of the next block
+                if (++tap == ntap) tap = 0; else c0 -= p.cb;   // next tap of the same block, or first tap of the next block
             }
         }
         if (!slow) {
@@ -823,6 +840,12 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
     // ---- epilogue: one wave-row group (WM rows of the tile) at a time through LDS ----
     h16* sC = reinterpret_cast<h16*>(smem);
     h16* Cb = p.C + bz * p.sC;
+    // phase form: row m = (b, y, x) of phase (py, px) lands on output pixel (2y + py, 2x + px) of the [B, 2H, 2W, N] tensor
+    const int ph_off = (MODE == 1 && p.phase) ? (int)(blockIdx.y >> 1) * 2 * p.Wd + (int)(blockIdx.y & 1) : 0;
+    auto out_row = [&](int m) -> long {
+        if (MODE == 1 && p.phase) { const int q = m / p.Wd; return 4L * p.Wd * q + 2 * (m - q * p.Wd) + ph_off; }
+        return m;
+    };
     const h16* Rb = p.resid ? p.resid + bz * p.sR : nullptr;
     constexpr int CPR = BN / 8;
     // whole C tile at once when it fits the ring's LDS, else one wave-row group per pass
@@ -1028,7 +1051,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
                     const int row = idx / cpr, ch = idx - row * cpr;
                     const int m = m0 + g * GR + row, n = nb + ch * 8;
                     const bool ok = idx < TOT && m < p.M && n < Nout;
-                    go[u] = ok ? (long)m * p.ldc + n : -1;
+                    go[u] = ok ? out_row(m) * p.ldc + n : -1;
                     lo[u] = row * CLD + ch * 8;
                     if (ok && Rb) r[u] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
                 }
@@ -1057,7 +1080,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
                 if (n + e < Nout) {
                     float f = (float)v[e];
                     if (Rb) f += (float)Rb[(long)m * p.ldr + n + e];
-                    Cb[(long)m * p.ldc + n + e] = (h16)f;
+                    Cb[out_row(m) * p.ldc + n + e] = (h16)f;
                 }
             }
         }
@@ -1212,7 +1235,7 @@ static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0
 
 // Can this conv run as a halo-resident tile of bm pixels with a halo image of hpa rows?  Returns the image rows per tile (0: no).
 static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
-    if (mode != 1 || p.cstride != 1 || p.pad != 1 || p.ups || p.cb != 64) return 0;
+    if (mode != 1 || p.cstride != 1 || p.pad != 1 || p.ups || p.phase || p.cb != 64) return 0;
     const int W = p.Wd, H = p.H;
     if (W < 8 || W > 128 || (W & (W - 1)) || bm % W || (p.M % bm)) return 0;
     const int th = bm / W < H ? bm / W : H;

@@ -319,6 +319,24 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
         raise _l.PbeError("conv3x3: x must be a contiguous [B,H,W,C] tensor")
     B, H, W, C1 = x.shape
     C2 = 0
+    if wp.dim() == 3:                            # pack_conv3x3_up_phases: the upsampling conv as four 2x2 convs on the source grid (4 / 9 of the MACs)
+        if not upsample or x2 is not None or resid is not None or rowvec is not None or stride != 1 or pad != 1:
+            raise _l.PbeError("conv3x3: phase-packed weights are for the plain nearest-2x upsampling conv")
+        if wp.shape[0] != 4 or not wp.is_contiguous() or wp.shape[2] != 4 * C1:
+            raise _l.PbeError(f"conv3x3: phase-packed weight must be [4, Cout, {4 * C1}], got {tuple(wp.shape)}")
+        Cout = wp.shape[1]
+        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float16, device=x.device)
+        if bias is not None:
+            _f(bias, "conv3x3 bias")
+        key = f"c:{B}:{H}:{W}:{C1}:0:{Cout}:1:1:2"
+        d = _l.Conv3x3Desc(_p(x), None, _p(wp), _p(y), _p(bias), None, None, B, H, W, C1, 0, Cout, 1, 1, 2, 0, act, _splitk_ws(x.device).data_ptr(),
+                           SPLITK_WS_BYTES, _tile_cfg(key), conv_kblock(C1, 0))
+        if _PIN_SCALE != 1:
+            d.tile_cfg = _pinned_cfg(d, lambda sc: f"c:{B * sc}:{H}:{W}:{C1}:0:{Cout}:1:1:2", True)
+        _launch_note(d, key, True)
+        with _timed(key):
+            _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16 (upsample, phase form)")
+        return y
     if x2 is not None:
         _h(x2, "conv3x3 x2")
         if x2.dim() != 4 or not x2.is_contiguous() or x2.shape[:3] != x.shape[:3]:
@@ -696,6 +714,33 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None, split: Optional
     assert not split or sum(split) == ci
     wp = wp.reshape(co, 9, ci // cb, cb).permute(0, 2, 1, 3)      # [Co, Ci/cb, 9, cb]
     return wp.reshape(co, 9 * ci).to(torch.float16).contiguous()
+
+
+def pack_conv3x3_up_phases(w: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 weight of a 3x3 conv that follows a nearest-2x upsample (openaimodel.py:109-119, model.py:44-53) -> fp16 [4, Cout, 4*Cin]:
+    output pixel (2y + py, 2x + px) reads only the 2x2 source block rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px}, so per phase
+    (py, px) the 9 taps collapse to 4 with summed weights (py = 0: ky {0} | {1, 2}; py = 1: ky {0, 1} | {2}; same in x), summed in fp32
+    before the single fp16 rounding.  K order per phase: k = ((ci // 64) * 4 + ty * 2 + tx) * 64 + ci % 64.  4 / 9 of the MACs of the fused
+    upsample gather."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and ci % 64 == 0
+    w32 = w.detach().float()
+    sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = []
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    acc = 0
+                    for ky in sets[py][ty]:
+                        for kx in sets[px][tx]:
+                            acc = acc + w32[:, :, ky, kx]
+                    taps.append(acc)                          # [Co, Ci]
+            wp = torch.stack(taps, 1)                         # [Co, 4, Ci]
+            wp = wp.reshape(co, 4, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, 4 * ci)
+            out.append(wp)
+    return torch.stack(out, 0).to(torch.float16).contiguous()
 
 
 def conv_kblock(c1: int, c2: int = 0) -> int:

@@ -343,6 +343,25 @@ def test_attention_softmax_spike(dev):
     _close(got, ref, rtol=4e-3, atol=2e-3, what="attention spike")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 128, 192), (1, 32, 32, 64, 64), (3, 8, 8, 320, 320), (1, 24, 40, 128, 128)])
+def test_upsample_conv_phase_form(dev, B, H, W, Cin, Cout):
+    """Nearest-2x upsample + 3x3 conv (openaimodel.py:109-119) as four 2x2 convs on the source grid (pbe_conv3x3_desc.upsample = 2,
+    ops.pack_conv3x3_up_phases): against torch fp32 interpolate + conv2d, and against the fused-gather form (upsample = 1) it replaces."""
+    from pbe_amd import ops
+    g = _g(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(F.interpolate(x.half().float(), scale_factor=2.0, mode="nearest"), w, b, padding=1).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    got = ops.conv3x3(xh, ops.pack_conv3x3_up_phases(w).to(dev), b.to(dev), upsample=True)
+    old = ops.conv3x3(xh, ops.pack_conv3x3(w).to(dev), b.to(dev), upsample=True)
+    assert got.shape == (B, 2 * H, 2 * W, Cout)
+    _close(got, ref, rtol=2e-3, atol=2e-3, what="upsample conv, phase form")
+    e_new, e_old = (got.float().cpu() - ref).norm() / ref.norm(), (old.float().cpu() - ref).norm() / ref.norm()
+    assert e_new <= 1.5 * e_old + 1e-4, (e_new, e_old)
+
+
 # ---- extended GEMM epilogue: the transformer block's chain (attention.py:198-252) in 5 launches --------------------------------------
 def _ln_ref(x, g, b, eps=1e-5):
     return F.layer_norm(x.float(), (x.shape[-1],), g, b, eps)

@@ -12,6 +12,7 @@ that the library clamps to the same effective plan (pbe_*_plan) are merged.
 """
 import argparse
 import json
+import re
 import os
 import statistics
 import sys
@@ -60,6 +61,7 @@ def main():
     ap.add_argument("--merge", default="", help="start from this table; shapes measured here replace their entries")
     ap.add_argument("--image-size", type=int, default=512, help="768 = BASELINE configs[4] geometry")
     ap.add_argument("--precision", default="fp16", choices=("fp16", "fp8"))
+    ap.add_argument("--only-regex", default="", help="keep only shape keys matching this regex (e.g. ':2$' = the phase-form upsampling convs); candidates: every tile, no split-K")
     ap.add_argument("--only-prefix", default="", help="keep only shape keys with this prefix (gx: = the extended-epilogue GEMMs); candidates are then its tiles only")
     a = ap.parse_args()
     import cases
@@ -80,6 +82,8 @@ def main():
             inp = {k: v.to(dev) for k, v in cases.synthetic_triples(B, a.image_size).items()}
             one_pass(model, inp, a.steps, -1)                                   # warm: packs, workspaces
             cands = [cfg | (sp << 8) for cfg in range(NCFG) for sp in SPLITS]
+            if a.only_regex:
+                cands = [cfg | (1 << 8) for cfg in range(NCFG)]
             if a.only_prefix == "gx:":                                            # extended epilogue: its instantiated tiles, never split-K
                 cands = [cfg | (1 << 8) for cfg in (3, 4, 5, 6, 8, 9, 15, 16, 17, 18)]
             data = {}                                                            # key -> {(cfg, splits): [us, ...]}
@@ -97,6 +101,8 @@ def main():
             tot_h = tot_b = 0.0
             for key in sorted(data):
                 if a.only_prefix and not key.startswith(a.only_prefix):
+                    continue
+                if a.only_regex and not re.search(a.only_regex, key):
                     continue
                 med = {eff: statistics.median(v) for eff, v in data[key].items()}
                 best = min(med, key=med.get)
