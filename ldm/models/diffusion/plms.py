@@ -103,7 +103,7 @@ class PLMSSampler(object):
             if self._graphed is None or self._graphed.unet is not unet:
                 self._graphed = GraphedUNet(unet)
             return self._graphed(x9, t, ctx, paired)
-        return unet.forward_nhwc(x9, t, ctx, paired=paired)
+        return unet.forward_nhwc(x9, t, ctx, paired=paired, step=int(step))      # every row of t is `step`: the embedding rows come from the per-value cache
 
     def _coef(self, index, weights):
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])

@@ -226,11 +226,13 @@ class UNetModel(HipModule):
             go=f32(self.out[0].weight), bo=f32(self.out[0].bias), eps_o=self.out[0].eps,
             w_out=ops.pack_conv3x3(self.out[2].weight), b_out=f32(self.out[2].bias))
         self.__dict__["_ctx_cache"] = None
+        self.__dict__["_emb_cache"] = {}
         return ns
 
     def invalidate_packs(self):
         super().invalidate_packs()
         self.__dict__["_ctx_cache"] = None
+        self.__dict__["_emb_cache"] = {}
 
     def context_vectors(self, context):
         """The 16 per-sample cross-attention constants for this context (cached while the same
@@ -256,7 +258,23 @@ class UNetModel(HipModule):
                 h = layer.run(h)
         return h
 
-    def forward_nhwc(self, x16, timesteps, context, paired=False):
+    def embedding_rows(self, step: int, device):
+        """Linear(SiLU(time_embed(t))) of all 22 emb_layers for ONE timestep value, [1, sum Cout] fp16, cached per value: inside a sampler
+        run every sample of every call shares the step's timestep (plms.py:144 torch_full), and the 50 schedule values recur for every batch,
+        so the three GEMMs + the sinusoid kernel (~55 us of launches per U-Net call, M = 2B rows of pure launch latency) run once per value
+        and weight set instead of 51 times per batch.  Same kernels, same bits as the per-call evaluation (a row of a GEMM does not depend on
+        the other rows).  Dropped with the packs."""
+        p = self.pk()
+        cache = self.__dict__.setdefault("_emb_cache", {})
+        row = cache.get((int(step), device))
+        if row is None:
+            t = torch.full((1,), int(step), device=device, dtype=torch.int64)
+            e = ops.gemm(timestep_embedding(t, self.model_channels), p.te0_w, p.te0_b, act=ops.ACT_SILU)
+            e = ops.gemm(e, p.te2_w, p.te2_b, act=ops.ACT_SILU)
+            row = cache[(int(step), device)] = ops.gemm(e, p.emb_w, p.emb_b)
+        return row
+
+    def forward_nhwc(self, x16, timesteps, context, paired=False, step=None):
         """x16 [B,H,W,cin_pad] fp16 (channels >= in_channels zero) -> eps [B,H,W,out_channels] fp16.
 
         paired=True is the classifier-free-guidance call of the samplers (plms.py:182-189): the reference feeds
@@ -269,10 +287,13 @@ class UNetModel(HipModule):
         (tools/layer_diff.py shows where un-pinned batch sizes part ways)."""
         p = self.pk()
         ctx = self.context_vectors(context)
-        t_emb = timestep_embedding(timesteps, self.model_channels)
-        e = ops.gemm(t_emb, p.te0_w, p.te0_b, act=ops.ACT_SILU)
-        e = ops.gemm(e, p.te2_w, p.te2_b, act=ops.ACT_SILU)          # SiLU(emb): emb is only ever consumed through SiLU
-        emb_all = ops.gemm(e, p.emb_w, p.emb_b)                        # all 22 emb_layers at once
+        if step is not None:                                           # the caller vouches that every entry of `timesteps` equals `step` (the samplers do)
+            emb_all = self.embedding_rows(step, x16.device).expand(timesteps.shape[0], -1)      # one cached row, stride-0 broadcast over the samples
+        else:
+            t_emb = timestep_embedding(timesteps, self.model_channels)
+            e = ops.gemm(t_emb, p.te0_w, p.te0_b, act=ops.ACT_SILU)
+            e = ops.gemm(e, p.te2_w, p.te2_b, act=ops.ACT_SILU)          # SiLU(emb): emb is only ever consumed through SiLU
+            emb_all = ops.gemm(e, p.emb_w, p.emb_b)                        # all 22 emb_layers at once
         blocks = list(self.input_blocks)[1:]
         if paired:
             B = x16.shape[0]

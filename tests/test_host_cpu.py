@@ -100,8 +100,9 @@ class _FakeUNet:
     def __init__(self, sd):
         self.sd, self.calls, self.batches = sd, 0, []
 
-    def forward_nhwc(self, x9, t, ctx, paired=False):
+    def forward_nhwc(self, x9, t, ctx, paired=False, step=None):
         self.calls += 1
+        assert step is not None and bool((t == int(step)).all())      # the samplers vouch that every row of t is `step` (cached embedding rows)
         if paired:                                   # shared-prefix guidance call: B inputs, 2B timesteps / contexts
             assert x9.shape[0] * 2 == t.shape[0] == ctx.shape[0]
             x9 = torch.cat([x9, x9])

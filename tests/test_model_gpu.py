@@ -195,6 +195,25 @@ def test_narrow_plms_key_spelling_and_ddim(dev, gold, narrow):
     check("DDIM 20-step latent", zd, g["ddim_latent"], 5e-3)                                # measured 1.7e-3
 
 
+def test_cached_timestep_embedding_rows_are_bit_identical(dev, narrow):
+    """UNetModel.forward_nhwc(step=t): the time-embedding MLP + the 22 emb_layers evaluated once per timestep VALUE and broadcast to the
+    samples (what the samplers pass) against the per-call evaluation on the [2B] timestep tensor - same kernels, same bits."""
+    from pbe_amd import ops
+    unet = narrow.model.diffusion_model
+    g = torch.Generator().manual_seed(31)
+    x = ops.nchw_to_nhwc(torch.randn(4, 9, 16, 16, generator=g).to(dev), unet.pk().cin_pad)
+    ctx = torch.randn(4, 1, 768, generator=g).to(dev).half()
+    with torch.no_grad():
+        for step in (981, 501, 981, 1):
+            t = torch.full((4,), step, dtype=torch.int64, device=dev)
+            a = unet.forward_nhwc(x, t, ctx)
+            b = unet.forward_nhwc(x, t, ctx, step=step)
+            assert torch.equal(a, b), step
+        assert len(unet.__dict__["_emb_cache"]) == 3
+        unet.invalidate_packs()
+        assert unet.__dict__["_emb_cache"] == {}
+
+
 def test_proj_out_pack_is_dropped_by_data_writes(dev):
     """ddpm.HipLinear caches its fp16 pack keyed on (data_ptr, _version); writes through ``.data`` - what shard.broadcast_weights_ and
     weights.fill_* do - do not move ``_version``, so those paths call ``invalidate_packs()`` on every module that has one: after it the
