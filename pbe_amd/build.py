@@ -29,7 +29,7 @@ EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          # SLP re-pairs the whole accumulator tile into (r0,r2)/(r1,r3) operands for v_pk_fma_f32 (no faster than v_fma_f32 on
          # gfx950, tools/ubench_valu.hip) above the epilogue: a second 128-160 VGPRs, i.e. scratch spills in the 256-row tiles.
          **{f: ["-fno-slp-vectorize"] for f in ("igemm.hip", "igemm_dense.hip", "igemm_conv.hip", "igemm_halo.hip", "igemm_f8.hip", "igemm_ex.hip", "igemm_ex_ln.hip",
-                                                  "igemm_ex_st.hip", "igemm_ex_qkv.hip", "igemm_ex_all.hip")}}
+                                                  "igemm_ex_st.hip", "igemm_ex_qkv.hip", "igemm_ex_all.hip", "igemm_astat.hip")}}
 
 
 def _hipcc() -> str:

@@ -1197,7 +1197,11 @@ static const TileCfg kCfg[] = {
     {128, 128, 2, 2, 1, 0.50},           // 15: S = 4, 128 KiB
     {128, 64, 2, 2, 1, 0.40},            // 16: S = 4,  96 KiB
     {64, 64, 2, 2, 2, 0.38},             // 17: S = 4,  64 KiB
-    {128, 160, 2, 2, 1, 0.52}};          // 18: S = 4, 144 KiB
+    {128, 160, 2, 2, 1, 0.52},           // 18: S = 4, 144 KiB
+    // A-stationary persistent tiles (igemm_astat.hip): K = 320 GEGLU projection with the LayerNorm fold, A block in registers, 4 waves,
+    // two workgroups per CU; never picked by the heuristic (eff 0), only through desc.tile_cfg / the tuned table where pbe_astat_ok() holds
+    {128, 128, 4, 1, 2, 0.0},            // 19: weight ring 48 KiB
+    {128, 160, 4, 1, 2, 0.0}};           // 20: weight ring 60 KiB (256 registers, 14 spilled)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 #ifdef PBE_STAMPS
@@ -1231,7 +1235,7 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
-static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1, 0.5, 0.4, 0.38, 0.52};
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1, 0.5, 0.4, 0.38, 0.52, 0.0, 0.0};
 
 // Can this conv run as a halo-resident tile of bm pixels with a halo image of hpa rows?  Returns the image rows per tile (0: no).
 static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
@@ -1247,7 +1251,8 @@ static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
 }
 
 // dense tiles that are instantiated with the extended epilogue (EX): the one-pass 4-wave tiles and 128x320
-static const unsigned kExCfgs = (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 15) | (1u << 16) | (1u << 17) | (1u << 18);
+static const unsigned kExCfgs = (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 15) | (1u << 16) | (1u << 17) | (1u << 18) | (3u << 19);
+bool pbe_astat_ok(const IGemmP& p, int batch, int cfg);      // igemm_astat.hip: can tile 19 run this problem?
 static inline bool ex_needed(const IGemmP& p) { return p.alpha_cols > 0 || p.ln_stat || p.rstat || p.vt; }
 
 // want_cfg: -1 = heuristic; else (tile config index) | (split-K factor << 8), factor 0 = heuristic factor for that tile.
@@ -1264,6 +1269,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];
+        if (c >= 19 && (forced != c || mode != 0 || !pbe_astat_ok(p, batch, c))) continue;
         if (ex_needed(p) && (!(kExCfgs >> c & 1) || (p.vt && p.vt_col0 % t.bn))) continue;   // extended epilogue: its tiles only, V^T columns start on a tile
         if (t.hpa && !halo_rows(p, mode, t.bm, t.hpa)) continue;              // a forced halo tile that does not apply falls back below
         if (t.hpa && p.N % 8) continue;
@@ -1352,3 +1358,4 @@ void pbe_launch_ex_ln(int cfg, IGemmP p, int batch, hipStream_t s);
 void pbe_launch_ex_st(int cfg, IGemmP p, int batch, hipStream_t s);
 void pbe_launch_ex_qkv(int cfg, IGemmP p, int batch, hipStream_t s);
 void pbe_launch_ex_all(int cfg, IGemmP p, int batch, hipStream_t s);
+void pbe_launch_astat(int cfg, IGemmP p, hipStream_t s);                                                  // tile 19 (igemm_astat.hip)

@@ -87,7 +87,7 @@ SYMBOLS = {
 _lib = None
 _lock = threading.Lock()
 
-SOURCES = ["runtime.hip", "igemm.hip", "igemm_dense.hip", "igemm_conv.hip", "igemm_halo.hip", "igemm_f8.hip", "igemm_ex.hip", "igemm_ex_ln.hip", "igemm_ex_st.hip", "igemm_ex_qkv.hip", "igemm_ex_all.hip", "attention.hip", "norm.hip",
+SOURCES = ["runtime.hip", "igemm.hip", "igemm_dense.hip", "igemm_conv.hip", "igemm_halo.hip", "igemm_f8.hip", "igemm_ex.hip", "igemm_ex_ln.hip", "igemm_ex_st.hip", "igemm_ex_qkv.hip", "igemm_ex_all.hip", "igemm_astat.hip", "attention.hip", "norm.hip",
            "elementwise.hip"]
 HASHED = [os.path.join("csrc", f) for f in SOURCES] + [os.path.join("csrc", "common.h"), os.path.join("csrc", "igemm_kernel.h"), os.path.join("..", "include", "pbe_hip.h"), "build.py"]
 

@@ -419,6 +419,41 @@ def test_gemm_layernorm_fold(dev, M, N, K, act):
     assert e_new <= 1.5 * e_old + 1e-4, (e_new, e_old)                      # no worse than the separate-LayerNorm path it replaces
 
 
+@pytest.mark.parametrize("M", [32768, 16384, 2048, 1280])
+def test_gemm_a_stationary_matches_streaming_tile(dev, M):
+    """Tile configs 19 / 20 (igemm_astat.hip: the K = 320 LayerNorm-folded GEGLU projection with the A block in registers and only the
+    weights streaming) against the streaming 128x160 tile: bit-identical (same accumulation order, same epilogue association), and against
+    torch fp32.  M = 1280 gives 10 row blocks - short runs, a ragged share of the chip."""
+    from pbe_amd import ops
+    K, N = 320, 2560
+    g = _g(M)
+    x = torch.randn(M, K, generator=g) * 1.3 + 0.4
+    x[: M // 4] += 6.0
+    x = x.half()
+    w, b = torch.randn(N, K, generator=g) / K ** 0.5, 0.1 * torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    h = F.linear(_ln_ref(x, gamma, beta), w, b)
+    Fh = N // 2
+    ref = h[:, :Fh] * F.gelu(h[:, Fh:])
+    wi, bi = torch.stack([w[:Fh], w[Fh:]], 1).reshape(N, K), torch.stack([b[:Fh], b[Fh:]], 1).reshape(N)
+    wg, c2, c1 = (t.to(dev) for t in ops.pack_linear_ln(wi, bi, gamma, beta))
+    xd = x.to(dev)
+    st = ops.row_stats(xd)
+    outs = {}
+    try:
+        for cfg in (9, 19, 20):
+            ops._FORCE_CFG = cfg
+            ops._PLANS = []
+            outs[cfg] = ops.gemm(xd, wg, c2, act=ops.ACT_GEGLU, ln=(st, c1, 1e-5))
+            assert ops._PLANS[0][1] == cfg, ops._PLANS                    # the forced tile really ran
+            again = ops.gemm(xd, wg, c2, act=ops.ACT_GEGLU, ln=(st, c1, 1e-5))
+            assert torch.equal(outs[cfg], again)
+    finally:
+        ops._FORCE_CFG, ops._PLANS = None, None
+    _close(outs[19], ref, rtol=3e-3, atol=3e-3, what=f"A-stationary GEGLU projection M={M}")
+    assert torch.equal(outs[19], outs[9]) and torch.equal(outs[20], outs[9])
+
+
 @pytest.mark.parametrize("B,N,C,heads", [(2, 256, 320, 8), (8, 64, 1280, 8), (1, 1024, 640, 8), (3, 256, 1280, 8)])
 def test_fused_qkv_projection_and_attention(dev, B, N, C, heads):
     """ONE launch for to_q | to_k | to_v with norm1 folded in, q pre-scaled by scale log2(e) in the fp32 epilogue and v stored transposed

@@ -139,3 +139,27 @@ def test_plms_call_count_100_steps():
     z = torch.zeros(1, 4, 2, 2)
     O.plms_sample(fake, 100, z, torch.zeros(1, 1, 8), None, 1.0, z, torch.zeros(1, 1, 2, 2), O.schedule_buffers()["alphas_cumprod"])
     assert n["c"] == 101
+
+
+def test_gelu_fit_constants():
+    """The HIP kernels' exact-GELU (pbe_amd/csrc/common.h gelu_erf_f: relu(x) - |x| exp2(-|x| R(|x|) - 1), R a degree-4 fit) against
+    x Phi(x) in float64 (torch.nn.functional.gelu's definition, the one the reference's GEGLU calls: ldm/modules/attention.py:46-53),
+    evaluated in float32 like the kernel: |error| <= 1e-6 over the whole range, no blow-up beyond the fitted range."""
+    import os
+    import re
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pbe_amd", "csrc", "common.h")).read()
+    c = [np.float32(float(re.search(rf"#define PBE_GELU_R{k} \(?(-?[0-9.e-]+)f\)?", src).group(1))) for k in range(5)]
+    assert c[4] > 0                                                  # q -> 0 far out
+    x = np.concatenate([np.linspace(-14, 14, 1000001), [0.0, 1e-8, -1e-8, 100, -100, 65504, -65504, 1e30, -1e30]]).astype(np.float32)
+    u = np.abs(x)
+    r = np.full_like(u, c[4])
+    with np.errstate(over="ignore"):
+        for k in (3, 2, 1, 0):
+            r = r * u + c[k]
+        y = np.maximum(x, np.float32(0)) - u * np.exp2(-u * r - np.float32(1))
+    x64 = x.astype(np.float64)
+    exact = x64 * 0.5 * (1.0 + erf(x64 / np.sqrt(2.0)))
+    assert np.isfinite(y).all()
+    err = np.abs(y.astype(np.float64) - exact)
+    assert (err <= np.maximum(1e-6, 2.0 ** -22 * np.abs(exact))).all(), err.max()
