@@ -22,13 +22,19 @@ namespace {
 constexpr int ABM = 128, AKT = 5;
 }  // namespace
 
-template <int TN>
+// FORM 0: GEGLU output (the FeedForward projection).  FORM 1: q | k | v^T of the fused self-attention projection - plain fp16 columns, alpha on
+// the columns below alpha_cols only, the tiles at and beyond vt_col0 stored transposed (IGemmP.vt), as the EX_LN | EX_VT streaming form does.
+template <int TN, int FORM>
 __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int run, int tiles_m) {
     constexpr int TM = 2, BN = 16 * TN, PW = BN / 8 / 4;          // PW = weight pieces (8 rows x 128 B) per wave and k-tile
     constexpr int SLOT = BN * 128, RS = 3;
     constexpr int STGR = BN / 2 + 8;                               // halfs per staging row
     constexpr int STGW = 16 * STGR * 2;
-    constexpr int NST = (16 * (BN / 16) + 63) / 64;                // store instructions per 16 rows (chunks of 16 bytes)
+    constexpr int NST = (16 * (BN / 16) + 63) / 64;                // store instructions per 16 rows x BN / 2 columns (chunks of 16 bytes)
+    constexpr int VROW = 40;                                       // halfs per row of the transposed staging (32 tokens + pad)
+    // stores a tile's epilogue leaves in the vmcnt queue: GEGLU 2 NST; plain 4 NST, transposed TN (the counted waits take the smaller)
+    constexpr int EST = FORM == 0 ? 2 * NST : (4 * NST < TN ? 4 * NST : TN);
+    static_assert(FORM == 0 || (TN % 2 == 0 && 32 * VROW * 2 <= 16 * (BN / 2 + 8) * 2), "transposed staging: two 16-column groups at a time");
     static_assert(BN % 32 == 0 && RS * SLOT + 4 * STGW + 2 * 2 * BN * 4 <= 80 * 1024, "two workgroups per CU");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -114,12 +120,15 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
         if (q + 2 < Q) issue_w();
         float vb = 0.f, vc = 0.f;
         if (kt == 2 && tid < BN) {                        // this tile's epilogue vectors -> LDS (read after the barriers of k-tiles 3 and 4)
-            vb = p.bias ? p.bias[n0 + tid] : 0.f;
-            vc = p.alpha * p.ln_c1[n0 + tid];             // alpha * colsum, as the streaming kernel's epilogue forms it
+            const int n = n0 + tid;
+            vb = p.bias ? p.bias[n] : 0.f;
+            vc = ((p.alpha_cols > 0 && n >= p.alpha_cols) ? 1.f : p.alpha) * p.ln_c1[n];      // alpha * colsum, as the streaming kernel's epilogue forms it
         }
         __builtin_amdgcn_sched_barrier(0);
         PBE_ACC(acc_r_);
         PBE_ACC_T0();
+        // (reading the 160-column tile's ten weight fragments five at a time does not lower the register count: the scheduler hoists the
+        //  second five - 26-31 spilled registers against 4-14)
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -147,46 +156,106 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // behind W(q) in this wave's queue at each wait: the next weight k-tile (PW pieces) and, for the first two k-tiles of a later tile, the
-        // previous epilogue's 2 NST stores (stores count in vmcnt on gfx950)
+        // previous epilogue's EST stores (stores count in vmcnt on gfx950)
         if (t == 0) {
             step(integral_constant<int, PW + 16>{}, integral_constant<int, 0>{}, n0, sbuf);
             step(integral_constant<int, PW>{}, integral_constant<int, 1>{}, n0, sbuf);
         } else {
-            step(integral_constant<int, PW + 2 * NST>{}, integral_constant<int, 0>{}, n0, sbuf);
-            step(integral_constant<int, PW + 2 * NST>{}, integral_constant<int, 1>{}, n0, sbuf);
+            step(integral_constant<int, PW + EST>{}, integral_constant<int, 0>{}, n0, sbuf);
+            step(integral_constant<int, PW + EST>{}, integral_constant<int, 1>{}, n0, sbuf);
         }
         step(integral_constant<int, PW>{}, integral_constant<int, 2>{}, n0, sbuf);
         step(integral_constant<int, PW>{}, integral_constant<int, 3>{}, n0, sbuf);
         step(integral_constant<int, PW>{}, integral_constant<int, 4>{}, n0, sbuf);
-        // ---- epilogue: LayerNorm fold + bias + GEGLU, 16 rows at a time through the wave's own staging rows (no workgroup barrier) ----
+        // ---- epilogue: LayerNorm fold + bias (+ GEGLU), 16 rows at a time through the wave's own staging rows (no workgroup barrier) ----
         PBE_ACC_T0();
         const float al = p.alpha;
         const float* sb = svec + sbuf * 2 * BN;
+        constexpr int CPR = BN / 16;                       // 16-byte chunks per staged row (BN / 2 halfs)
+        if constexpr (FORM == 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const float ars = al * ln_rs[j];
+            for (int j = 0; j < TM; ++j) {
+                const float ars = al * ln_rs[j];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const f32x4 bn = *reinterpret_cast<const f32x4*>(sb + i * 16 + fq * 4);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(sb + BN + i * 16 + fq * 4);
-                float v[4];
+                for (int i = 0; i < TN; ++i) {
+                    const f32x4 bn = *reinterpret_cast<const f32x4*>(sb + i * 16 + fq * 4);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(sb + BN + i * 16 + fq * 4);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ars, __builtin_fmaf(ln_nm[j], c1[r], bn[r]));
+                    const h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
+                    *reinterpret_cast<h16x2*>(stg + fr * STGR + i * 8 + fq * 2) = o2;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < NST; ++h) {
+                    const int idx = lane + 64 * h;
+                    if (idx < 16 * CPR) {
+                        const int row = idx / CPR, ch = idx - row * CPR;
+                        const h16x8 val = *reinterpret_cast<const h16x8*>(stg + row * STGR + ch * 8);
+                        *reinterpret_cast<h16x8*>(p.C + (long)(m0 + wm * 32 + j * 16 + row) * p.ldc + (n0 >> 1) + ch * 8) = val;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            auto value = [&](int i, int j, float (&v)[4]) {           // the streaming kernel's EX_LN | EX_VT expression, same association
+                const int nl = i * 16 + fq * 4;
+                const float ali = (p.alpha_cols > 0 && n0 + nl >= p.alpha_cols) ? 1.f : al;
+                const f32x4 bn = *reinterpret_cast<const f32x4*>(sb + nl);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(sb + BN + nl);
+                const float ars = ali * ln_rs[j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[i][j][r], ars, __builtin_fmaf(ln_nm[j], c1[r], bn[r]));
-                const h16x2 o2 = {(h16)(v[0] * gelu_erf_f(v[1])), (h16)(v[2] * gelu_erf_f(v[3]))};
-                *reinterpret_cast<h16x2*>(stg + fr * STGR + i * 8 + fq * 2) = o2;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int CPR = BN / 16;                   // 16-byte chunks per output row
+            };
+            if (!(p.vt && n0 >= p.vt_col0)) {                        // q | k columns: rows of BN / 2 columns at a time
 #pragma unroll
-            for (int h = 0; h < NST; ++h) {
-                const int idx = lane + 64 * h;
-                if (idx < 16 * CPR) {
-                    const int row = idx / CPR, ch = idx - row * CPR;
-                    const h16x8 val = *reinterpret_cast<const h16x8*>(stg + row * STGR + ch * 8);
-                    *reinterpret_cast<h16x8*>(p.C + (long)(m0 + wm * 32 + j * 16 + row) * p.ldc + (n0 >> 1) + ch * 8) = val;
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                        for (int ii = 0; ii < TN / 2; ++ii) {
+                            float v[4];
+                            value(hf * (TN / 2) + ii, j, v);
+                            const h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                            *reinterpret_cast<h16x4*>(stg + fr * STGR + ii * 16 + fq * 4) = o;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int h = 0; h < NST; ++h) {
+                            const int idx = lane + 64 * h;
+                            if (idx < 16 * CPR) {
+                                const int row = idx / CPR, ch = idx - row * CPR;
+                                const h16x8 val = *reinterpret_cast<const h16x8*>(stg + row * STGR + ch * 8);
+                                *reinterpret_cast<h16x8*>(p.C + (long)(m0 + wm * 32 + j * 16 + row) * p.ldc + n0 + hf * (BN / 2) + ch * 8) = val;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+            } else {                                                  // v columns: [channel][token] through the staging, 32 channels x the wave's 32 tokens at a time
+                const int mw = m0 + wm * 32, bsmp = mw / p.vt_tok, tok0 = mw - bsmp * p.vt_tok;      // (32 | vt_tok: one sample per wave)
+                h16* vdst = p.vt + (long)bsmp * p.vt_bs + tok0;
+#pragma unroll
+                for (int ps = 0; ps < TN / 2; ++ps) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) {
+                            float v[4];
+                            value(ps * 2 + ii, j, v);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) stg[(ii * 16 + fq * 4 + r) * VROW + j * 16 + fr] = (h16)v[r];
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int idx = lane + 64 * h, crow = idx >> 2, tch = idx & 3;
+                        const h16x8 val = *reinterpret_cast<const h16x8*>(stg + crow * VROW + tch * 8);
+                        *reinterpret_cast<h16x8*>(vdst + (long)(n0 - p.vt_col0 + ps * 32 + crow) * p.vt_rs + tch * 8) = val;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         PBE_ACC(acc_b1_);
     }
@@ -195,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
     PBE_STAMP(8);
 }
 
-template <int TN>
+template <int TN, int FORM>
 static void launch_regs(IGemmP p, hipStream_t s) {
     constexpr int BN = 16 * TN;
     constexpr int lds = 3 * BN * 128 + 4 * 16 * (BN / 2 + 8) * 2 + 2 * 2 * BN * 4;
@@ -203,20 +272,25 @@ static void launch_regs(IGemmP p, hipStream_t s) {
     int run = tiles_n;                                     // the longest run of column tiles that still gives every CU its two workgroups
     while (run > 1 && ((long)tiles_m * (tiles_n / run) < 512 || tiles_n % run)) --run;
     static std::atomic<uint64_t> attr_done{0};
-    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&astat_regs_kernel<TN>), lds);
+    pbe_raise_dynamic_lds(attr_done, reinterpret_cast<const void*>(&astat_regs_kernel<TN, FORM>), lds);
     pbe_prof_begin(PBE_K_GEMM, s);
-    hipLaunchKernelGGL(astat_regs_kernel<TN>, dim3((unsigned)(tiles_m * (tiles_n / run))), dim3(256), lds, s, p, run, tiles_m);
-    pbe_prof_end(PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * 0.5));
+    hipLaunchKernelGGL((astat_regs_kernel<TN, FORM>), dim3((unsigned)(tiles_m * (tiles_n / run))), dim3(256), lds, s, p, run, tiles_m);
+    const double nout = FORM == 0 ? 0.5 * p.N : (double)p.N;
+    pbe_prof_end(PBE_K_GEMM, s, 2.0 * p.M * (double)p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * nout));
 }
 
-
+// Tile 19 = 128 columns, tile 20 = 160 columns.  GEGLU with the LayerNorm fold, or (tile 20) the fused q | k | v^T projection.
 bool pbe_astat_ok(const IGemmP& p, int batch, int cfg) {
     const int bn = cfg == 19 ? 128 : 160;
-    return batch == 1 && !p.A2 && p.K == 64 * AKT && p.M % ABM == 0 && p.N % bn == 0 && p.act == PBE_ACT_GEGLU && p.ln_stat && !p.rstat && !p.vt &&
-           p.alpha_cols == 0 && !p.resid && !p.rowvec && !p.bias_row && p.vec && (p.lda & 7) == 0 && (p.ldw & 7) == 0;
+    if (!(batch == 1 && !p.A2 && p.K == 64 * AKT && p.M % ABM == 0 && p.N % bn == 0 && p.ln_stat && !p.rstat && !p.resid && !p.rowvec && !p.bias_row && p.vec &&
+          (p.lda & 7) == 0 && (p.ldw & 7) == 0))
+        return false;
+    if (p.act == PBE_ACT_GEGLU) return !p.vt && p.alpha_cols == 0;
+    return cfg == 20 && p.act == PBE_ACT_NONE && p.vt && p.vt_col0 % bn == 0 && p.vt_tok % 32 == 0 && (p.alpha_cols & 3) == 0 && (p.ldc & 7) == 0;
 }
 
 void pbe_launch_astat(int cfg, IGemmP p, hipStream_t s) {
-    if (cfg == 19) launch_regs<8>(p, s);
-    else launch_regs<10>(p, s);
+    if (p.act != PBE_ACT_GEGLU) launch_regs<10, 1>(p, s);
+    else if (cfg == 19) launch_regs<8, 0>(p, s);
+    else launch_regs<10, 0>(p, s);
 }

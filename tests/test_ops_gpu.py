@@ -454,6 +454,40 @@ def test_gemm_a_stationary_matches_streaming_tile(dev, M):
     assert torch.equal(outs[19], outs[9]) and torch.equal(outs[20], outs[9])
 
 
+@pytest.mark.parametrize("B,N", [(8, 4096), (4, 4096), (3, 1024), (2, 160)])
+def test_gemm_a_stationary_qkv_matches_streaming_tile(dev, B, N):
+    """Tile 20 on the fused q | k | v^T projection (K = 320, LayerNorm folded, alpha on the q columns only, v stored transposed) against the
+    streaming 128x160 tile: bit-identical q | k and V^T, and against torch fp32.  N = 160 tokens: 32 | N but a 128-row block spans samples."""
+    from pbe_amd import ops
+    C, M = 320, B * N
+    g = _g(M + 3)
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.4).half()
+    w, b = torch.randn(3 * C, C, generator=g) / C ** 0.5, 0.1 * torch.randn(3 * C, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.linear(_ln_ref(x, gamma, torch.zeros(C)), w)                    # alpha scales the product, not the folded bias W beta + b
+    ref[:, :C] *= 0.2281
+    ref += w @ beta + b
+    wg, c2, c1 = (t.to(dev) for t in ops.pack_linear_ln(w, b, gamma, beta))
+    xd = x.to(dev)
+    st = ops.row_stats(xd)
+    outs = {}
+    try:
+        for cfg in (9, 20):
+            ops._FORCE_CFG = cfg
+            ops._PLANS = []
+            qk = torch.zeros(M, 2 * C, dtype=torch.float16, device=dev)
+            vt = torch.zeros(B, C, N, dtype=torch.float16, device=dev)
+            ops.gemm(xd, wg, c2, ln=(st, c1, 1e-5), alpha=0.2281, alpha_cols=C, out=qk, vt=vt, vt_col0=2 * C, vt_tokens=N)
+            if M % 128 == 0:
+                assert ops._PLANS[0][1] == cfg, ops._PLANS
+            outs[cfg] = (qk, vt)
+    finally:
+        ops._FORCE_CFG, ops._PLANS = None, None
+    assert torch.equal(outs[20][0], outs[9][0]) and torch.equal(outs[20][1], outs[9][1])
+    _close(outs[20][0], ref[:, :2 * C], rtol=3e-3, atol=3e-3, what="q | k")
+    _close(outs[20][1].transpose(1, 2).reshape(M, C), ref[:, 2 * C:], rtol=3e-3, atol=3e-3, what="v^T")
+
+
 @pytest.mark.parametrize("B,N,C,heads", [(2, 256, 320, 8), (8, 64, 1280, 8), (1, 1024, 640, 8), (3, 256, 1280, 8)])
 def test_fused_qkv_projection_and_attention(dev, B, N, C, heads):
     """ONE launch for to_q | to_k | to_v with norm1 folded in, q pre-scaled by scale log2(e) in the fp32 epilogue and v stored transposed
