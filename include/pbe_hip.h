@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PBE_ABI_VERSION 7
+#define PBE_ABI_VERSION 8
 
 #define PBE_OK 0
 #define PBE_EINVAL (-1)  /* bad shape / alignment / null pointer          */
@@ -157,6 +157,15 @@ typedef struct pbe_conv3x3_desc {
     int32_t tile_cfg;       /* -1 = heuristic, else tile config | (split-K factor << 8), as in pbe_gemm_desc */
     int32_t kblock;         /* channel block cb of Wp's K order: k = ((ci/cb)*9 + tap)*cb + ci%cb; multiple of 64 that
                                divides C1 and C2 (0 = 64).  A pixel's 9 taps are then re-read within 9*cb/64 k-tiles (L2 hits) */
+    /* Y feeds a GroupNorm (ResBlock: conv -> GroupNorm32 -> SiLU, openaimodel.py:213-227; the block's output -> the next normalisation):
+     * group_stats_out != NULL asks the conv's copy-out for the per-(sample, row block, group) partial (sum, sumsq) of the STORED fp16
+     * values, in pbe_groupnorm_f16's partial layout [B][blocks][group_stats_groups][2] (fp32; size it for blocks <= Ho*Wo / 64).
+     * *group_stats_blocks (host int, written before the call returns) = blocks per sample actually produced, or 0 when the planned tile
+     * cannot (split-K, a tile that is not whole groups of one sample, multi-pass epilogue): the caller then runs pbe_groupnorm_f16,
+     * else pbe_groupnorm_apply_f16 with these partials.  Fixed summation order: bit-reproducible run to run. */
+    float* group_stats_out;
+    int32_t group_stats_groups;
+    int32_t* group_stats_blocks;
 } pbe_conv3x3_desc;
 int pbe_conv3x3_f16(const pbe_conv3x3_desc* d, pbe_stream_t stream);
 int pbe_conv3x3_plan(const pbe_conv3x3_desc* d, int32_t* out6, size_t* workspace_needed); /* as pbe_gemm_plan */
@@ -177,6 +186,10 @@ size_t pbe_groupnorm_workspace_bytes(int32_t B, int32_t HW);
 int pbe_groupnorm_f16(const void* X, const void* X2, const float* gamma, const float* beta, void* Y,
                       int32_t B, int32_t HW, int32_t C1, int32_t C2, int32_t groups, float eps,
                       int32_t silu, void* workspace, size_t workspace_bytes, pbe_stream_t stream);
+/* The normalisation pass alone, statistics given as partials [B][blocks][groups][2] (sum, sumsq) - from pbe_conv3x3_f16's
+ * group_stats_out.  Single source (no concat), any map size. */
+int pbe_groupnorm_apply_f16(const void* X, const float* partials, int32_t blocks, const float* gamma, const float* beta, void* Y,
+                            int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, int32_t silu, pbe_stream_t stream);
 
 /* pbe_layernorm_f16 — LayerNorm over the last dim C (C % 8 == 0, C <= 2048) of fp16 rows.
  * Replaces attention.py:240-242 (norm1/3), xf.py:22-28, HF CLIP layer norms. */

@@ -109,7 +109,9 @@ class ResBlock(HipModule, TimestepBlock):
         p = self.pk()
         B, H, W, C1 = x.shape
         # GroupNorm reads the concat pair in place and writes the normalised concat as ONE tensor: the conv has a single source
-        h = ops.conv3x3(ops.groupnorm(x, p.g1, p.b1, p.eps1, True, x2=skip), p.w1, p.cb1, rowvec=emb_out)
+        # (group_stats: the conv's copy-out leaves the statistics of the GroupNorm32 that reads its output - out_layers[0] here, the next
+        #  block's or the transformer's norm for the block output - so that norm runs its normalisation pass only; openaimodel.py:213-227)
+        h = ops.conv3x3(ops.groupnorm(x, p.g1, p.b1, p.eps1, True, x2=skip), p.w1, p.cb1, rowvec=emb_out, group_stats=32)
         h = ops.groupnorm(h, p.g2, p.b2, p.eps2, True)
         if p.ws is not None:
             a2 = None if skip is None else skip.view(B * H * W, -1)
@@ -118,7 +120,7 @@ class ResBlock(HipModule, TimestepBlock):
             raise PbeError("ResBlock: identity skip with a concat input is impossible (channel mismatch)")
         else:
             xs = x
-        return ops.conv3x3(h, p.w2, p.cb2, resid=xs)
+        return ops.conv3x3(h, p.w2, p.cb2, resid=xs, group_stats=32)
 
     def emb_out(self, emb):
         """emb [B, emb_channels] (pre-SiLU, as the reference passes it) -> [B, Cout] fp16."""

@@ -19,6 +19,8 @@ extern "C" int pbe_tune(int32_t key, int32_t value) {
     if (key == 5) { g_pbe_mfast = value ? 1 : 0; return PBE_OK; }
     if (key == 8) { extern int g_pbe_attn_pad_lds; g_pbe_attn_pad_lds = value > 0 ? value : 0; return PBE_OK; }
     if (key == 7) { extern int g_pbe_gn_rows; g_pbe_gn_rows = value >= 1 ? value : 16; return PBE_OK; }
+    if (key == 10) { extern int g_pbe_gn_apply2_rows; g_pbe_gn_apply2_rows = value >= 0 ? value : 8; return PBE_OK; }
+    if (key == 9) { extern int g_pbe_gn_apply_rows; g_pbe_gn_apply_rows = value >= 1 ? value : 4; return PBE_OK; }
     if (key == 6) { extern int g_pbe_attn_mpad; g_pbe_attn_mpad = value ? 1 : 0; return PBE_OK; }
     return pbe_set_error(PBE_EINVAL, "pbe_tune: unknown key %d", key);
 }
@@ -151,6 +153,13 @@ static int fill_conv(const pbe_conv3x3_desc* d, IGemmP& p, const char* who) {
     p.cb = d->kblock > 0 ? d->kblock : 64;
     PBE_REQUIRE(p.cb % 64 == 0 && d->C1 % p.cb == 0 && d->C2 % p.cb == 0, "%s: kblock=%d must be a multiple of 64 dividing C1=%d and C2=%d", who, p.cb, d->C1, d->C2);
     p.ws = (float*)d->workspace;
+    if (d->group_stats_blocks) *d->group_stats_blocks = 0;
+    if (d->group_stats_out) {
+        PBE_REQUIRE(d->group_stats_blocks && d->group_stats_groups > 0 && d->group_stats_groups <= 64 && d->Cout % d->group_stats_groups == 0,
+                    "%s: group_stats_out needs group_stats_blocks and 0 < group_stats_groups <= 64 dividing Cout", who);
+        p.gstat = d->group_stats_out; p.gs_groups = d->group_stats_groups; p.gs_cg = d->Cout / d->group_stats_groups; p.gs_hw = Ho * Wo;
+        p.gs_report = d->group_stats_blocks;
+    }
     return PBE_OK;
 }
 

@@ -59,6 +59,10 @@ struct IGemmP {
     float* rstat;                    // this launch's OUTPUT rows feed a LayerNorm: per (column tile, row) partial (sum, sumsq) of the stored fp16 values
     h16* vt; int vt_col0, vt_tok;    // columns n >= vt_col0 are stored TRANSPOSED: vt[b * vt_bs + (n - vt_col0) * vt_rs + tok], m = b * vt_tok + tok
     long vt_bs, vt_rs;               //   (V^T for the attention kernel from the same launch as q | k)
+    // conv output feeds a GroupNorm: per (sample, row block of the tile grid, group) partial (sum, sumsq) of the STORED fp16 values (after the
+    // residual add), in pbe_groupnorm_f16's partial layout [B][blocks][groups][2] - the norm's statistics pass is then not launched
+    float* gstat; int gs_cg, gs_groups, gs_hw;      // channels per group, groups of the whole tensor, output pixels per sample
+    int* gs_report;                                 // HOST pointer (launch_cfg): row blocks per sample the launch writes partials for, 0 = this tile cannot
     int sv_ok;      // bias + row vector of a tile come from LDS (set per tile shape in launch_cfg)
     int m_fast;     // an XCD's run of tiles walks m fastest (one weight panel, many activation rows) instead of n fastest (launch_cfg)
 #ifdef PBE_STAMPS
@@ -851,6 +855,9 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
     // whole C tile at once when it fits the ring's LDS, else one wave-row group per pass
     constexpr bool ONE_PASS = (size_t)BM * CLD * 2 <= (size_t)S * STAGE;
     constexpr int NG = ONE_PASS ? 1 : NWM;            // passes
+    // GroupNorm statistics from the copy-out (convs, whole-tile epilogues): scratch behind the C tile, inside the ring's LDS
+    constexpr int GS_OFF = (BM * CLD * 2 + 15) & ~15;
+    constexpr bool GS_OK = MODE != 0 && ONE_PASS && !F8 && (NT / (BN / 8)) >= 1 && (size_t)GS_OFF + ((size_t)(NT / (BN / 8)) * BN + BN) * 8 <= (size_t)RING;
     constexpr int GR = ONE_PASS ? BM : WM;            // rows per pass
     // The register -> LDS half has a compile-time FAST path (bias / row vector staged in svec, one sample per tile, no
     // per-row bias): the generic form (per-element bounds checks, global bias loads and row-vector gathers with an
@@ -1036,6 +1043,65 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
 #pragma unroll
                     for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
                     if (rok && l8 == 0) *reinterpret_cast<float2*>(p.rstat + 2 * ((long)tn_i * p.rstat_ld + m)) = make_float2(s1, s2);
+                }
+                return;
+            }
+        }
+        if constexpr (GS_OK && !gg) {
+            if (p.gstat) {
+                // GroupNorm statistics of this tile's stored values.  A thread keeps ONE 16-byte column chunk and walks rows (slot, slot + RSL,
+                // ...): 8 column sums + 8 sums of squares in registers, then a fixed-order fold over the row slots and over a group's columns
+                // through LDS (no atomics: bit-reproducible).  Row batches of 4: the residual loads of a batch are issued together.
+                constexpr int RSL = NT / CPR, GB = 4;
+                float* red = reinterpret_cast<float*>(smem + GS_OFF);
+                const int slot = tid / CPR, ch = tid - slot * CPR, n = n0 + ch * 8;
+                float ca[8], cq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ca[e] = 0.f; cq[e] = 0.f; }
+                if (slot < RSL && n < p.N) {
+                    for (int r0 = slot; r0 < GR; r0 += RSL * GB) {
+                        h16x8 v[GB], r[GB];
+                        bool ok[GB];
+#pragma unroll
+                        for (int u = 0; u < GB; ++u) {
+                            const int row = r0 + u * RSL, m = m0 + row;
+                            ok[u] = row < GR && m < p.M;
+                            if (ok[u] && Rb) r[u] = *reinterpret_cast<const h16x8*>(Rb + (long)m * p.ldr + n);
+                        }
+#pragma unroll
+                        for (int u = 0; u < GB; ++u)
+                            if (ok[u]) v[u] = *reinterpret_cast<const h16x8*>(sC + (r0 + u * RSL) * CLD + ch * 8);
+#pragma unroll
+                        for (int u = 0; u < GB; ++u) {
+                            if (!ok[u]) continue;
+                            if (Rb) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[u][e] = (h16)((float)v[u][e] + (float)r[u][e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; ca[e] += f; cq[e] = __builtin_fmaf(f, f, cq[e]); }
+                            *reinterpret_cast<h16x8*>(Cb + out_row(m0 + r0 + u * RSL) * p.ldc + n) = v[u];
+                        }
+                    }
+                }
+                if (slot < RSL) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) *reinterpret_cast<float2*>(red + ((slot * BN) + ch * 8 + e) * 2) = make_float2(ca[e], cq[e]);
+                }
+                __syncthreads();
+                float* col = red + RSL * BN * 2;               // [BN][2] column totals
+                if (tid < BN) {
+                    float a = 0.f, q = 0.f;
+                    for (int sl = 0; sl < RSL; ++sl) { const float2 t = *reinterpret_cast<const float2*>(red + (sl * BN + tid) * 2); a += t.x; q += t.y; }
+                    *reinterpret_cast<float2*>(col + tid * 2) = make_float2(a, q);
+                }
+                __syncthreads();
+                const int cg = p.gs_cg, gl = tid;               // group gl of this tile's BN / cg
+                if (gl * cg < BN && n0 + gl * cg < p.N) {
+                    float a = 0.f, q = 0.f;
+                    for (int c = gl * cg; c < (gl + 1) * cg; ++c) { const float2 t = *reinterpret_cast<const float2*>(col + c * 2); a += t.x; q += t.y; }
+                    const int b = m0 / p.gs_hw, blk = (m0 - b * p.gs_hw) / BM, nblk = p.gs_hw / BM;
+                    *reinterpret_cast<float2*>(p.gstat + (((long)b * nblk + blk) * p.gs_groups + n0 / cg + gl) * 2) = make_float2(a, q);
                 }
                 return;
             }
@@ -1327,6 +1393,15 @@ static void launch_cfg(IGemmP p, int batch, hipStream_t s) {
         const double n_fast = a_bytes * frac(run / tiles_n + 1.0, tiles_m) + w_bytes * frac(run, tiles_n);
         const double m_fast = w_bytes * frac(run / tiles_m + 1.0, tiles_n) + a_bytes * frac(run, tiles_m);
         p.m_fast = (g_pbe_mfast && batch == 1 && m_fast < 0.9 * n_fast) ? 1 : 0;
+    }
+    {   // GroupNorm statistics from the copy-out: only where the kernel's GS_OK holds and a tile is a whole number of groups inside one sample
+        constexpr int NTH = NWM * NWN * 64;
+        constexpr bool one_pass = (size_t)BM * (BN + 8) * 2 <= (size_t)S * (BM + BN) * 128;
+        constexpr size_t gs_off = ((size_t)BM * (BN + 8) * 2 + 15) & ~(size_t)15;
+        constexpr bool gs_ok = MODE != 0 && one_pass && !F8 && gs_off + ((size_t)(NTH / (BN / 8)) * BN + BN) * 8 <= ring;
+        if (p.gstat && !(gs_ok && p.splits <= 1 && batch == 1 && p.gs_cg > 0 && p.gs_hw % BM == 0 && BN % p.gs_cg == 0 && !p.phase && p.vec && p.act != PBE_ACT_GEGLU))
+            p.gstat = nullptr;
+        if (p.gs_report) *p.gs_report = p.gstat ? p.gs_hw / BM : 0;
     }
     // profiling brackets exactly ONE kernel each, so the event averages agree with rocprofv3's per-kernel averages
     if (MODE == 2) p.th = BM / p.Wd < p.H ? BM / p.Wd : p.H;

@@ -208,11 +208,13 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const h16* X, const h16* 
 }
 
 int g_pbe_gn_rows = 16;      // pbe_tune(7, n): rows per thread of the two-pass GroupNorm kernels (developer knob)
-static void gn_geometry(int HW, int C, int* nchunks, int* rpb, int* TX, int* TY) {
+int g_pbe_gn_apply2_rows = 8; // pbe_tune(10, n): rows per thread of the two-pass norm's normalisation pass (0 = the statistics pass's geometry); 8: -2..4 % with the input resident
+int g_pbe_gn_apply_rows = 4; // pbe_tune(9, n): rows per thread of the normalisation pass when the statistics come from the producing conv
+static void gn_geometry(int HW, int C, int* nchunks, int* rpb, int* TX, int* TY, int rows_per_thread = 0) {
     const int C8 = C / 8;
     *TX = C8 < 256 ? C8 : 256;
     *TY = 256 / *TX;
-    int rows = *TY * g_pbe_gn_rows;           // 16 rows per thread: four 4-deep load batches
+    int rows = *TY * (rows_per_thread > 0 ? rows_per_thread : g_pbe_gn_rows);           // 16 rows per thread: four 4-deep load batches
     if (rows < 32) rows = 32;
     int n = (HW + rows - 1) / rows;
     if (n > GN_MAX_CHUNKS) { n = GN_MAX_CHUNKS; rows = (HW + n - 1) / n; n = (HW + rows - 1) / rows; }
@@ -250,10 +252,32 @@ extern "C" int pbe_groupnorm_f16(const void* X, const void* X2, const float* gam
     pbe_prof_begin(PBE_K_GNORM, s);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (float*)workspace, HW, C1, C2,
                        groups, rpb, TX, TY);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (const float*)workspace, gamma,
-                       beta, (h16*)Y, HW, C1, C2, groups, nchunks, rpb, TX, TY, eps, silu);
+    {   // the normalisation pass runs a finer grid than the statistics pass (pbe_tune(10, rows per thread), 0 = the statistics pass's geometry)
+        int ac = nchunks, arpb = rpb, aTX = TX, aTY = TY;
+        if (g_pbe_gn_apply2_rows > 0) gn_geometry(HW, C, &ac, &arpb, &aTX, &aTY, g_pbe_gn_apply2_rows);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(ac, B), dim3(256), 0, s, (const h16*)X, (const h16*)X2, (const float*)workspace, gamma,
+                           beta, (h16*)Y, HW, C1, C2, groups, nchunks, arpb, aTX, aTY, eps, silu);
+    }
     pbe_prof_end(PBE_K_GNORM, s, 6.0 * B * (double)HW * C);   // bytes: read x twice, write y once
     PBE_LAUNCH_CHECK("pbe_groupnorm_f16");
+    return PBE_OK;
+}
+
+extern "C" int pbe_groupnorm_apply_f16(const void* X, const float* partials, int32_t blocks, const float* gamma, const float* beta, void* Y,
+                                       int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, int32_t silu, pbe_stream_t stream) {
+    PBE_REQUIRE(X && partials && gamma && beta && Y, "pbe_groupnorm_apply_f16: null operand");
+    PBE_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0 && C % 8 == 0 && C <= GN_MAX_C && blocks > 0, "pbe_groupnorm_apply_f16: bad dims");
+    PBE_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "pbe_groupnorm_apply_f16: groups=%d must divide C=%d (<= 64)", groups, C);
+    hipStream_t s = (hipStream_t)stream;
+    // (the finalise prologue of a workgroup reads `blocks` partials per group - 16 at 64x64, not one per chunk of this grid - so short
+    //  workgroups are cheap here: 4 rows per thread = 5 workgroups per CU at [8, 4096, 320] against 1.3 with the two-pass geometry)
+    int nchunks, rpb, TX, TY;
+    gn_geometry(HW, C, &nchunks, &rpb, &TX, &TY, g_pbe_gn_apply_rows);
+    pbe_prof_begin(PBE_K_GNORM, s);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, (const h16*)X, (const h16*)nullptr, partials, gamma, beta, (h16*)Y, HW, C, 0,
+                       groups, blocks, rpb, TX, TY, eps, silu);
+    pbe_prof_end(PBE_K_GNORM, s, 4.0 * B * (double)HW * C);   // bytes: read x once, write y once
+    PBE_LAUNCH_CHECK("pbe_groupnorm_apply_f16");
     return PBE_OK;
 }
 

@@ -8,7 +8,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBE_LIB_PATH") or os.path.join(_HERE, "libpbe_hip.so")     # PBE_LIB_PATH: diagnostic builds (tools/) only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -30,7 +30,8 @@ class Conv3x3Desc(C.Structure):
     _fields_ = [("X", c_vp), ("X2", c_vp), ("Wp", c_vp), ("Y", c_vp), ("bias", c_vp), ("rowvec", c_vp), ("resid", c_vp),
                 ("B", c_i32), ("H", c_i32), ("W", c_i32), ("C1", c_i32), ("C2", c_i32), ("Cout", c_i32),
                 ("stride", c_i32), ("pad", c_i32), ("upsample", c_i32), ("ldv", c_i32), ("act", c_i32),
-                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32), ("kblock", c_i32)]
+                ("workspace", c_vp), ("workspace_bytes", c_sz), ("tile_cfg", c_i32), ("kblock", c_i32),
+                ("group_stats_out", c_vp), ("group_stats_groups", c_i32), ("group_stats_blocks", c_vp)]
 
 
 class AttnDesc(C.Structure):
@@ -55,6 +56,7 @@ SYMBOLS = {
     "pbe_im2col3x3_f16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "pbe_groupnorm_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "pbe_groupnorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp, c_sz, c_vp]),
+    "pbe_groupnorm_apply_f16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "pbe_layernorm_f16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),
     "pbe_row_stats_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp]),
     "pbe_layernorm_f8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_f32, c_vp]),

@@ -312,8 +312,11 @@ def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool) -> Tuple[
 
 def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, x2: Optional[torch.Tensor] = None,
             rowvec: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1,
-            upsample: bool = False, act: int = ACT_NONE) -> torch.Tensor:
-    """NHWC 3x3 conv on the matrix cores; ``wp`` is the packed [Cout, 9*Cin] weight (pack_conv3x3)."""
+            upsample: bool = False, act: int = ACT_NONE, group_stats: int = 0) -> torch.Tensor:
+    """NHWC 3x3 conv on the matrix cores; ``wp`` is the packed [Cout, 9*Cin] weight (pack_conv3x3).
+    group_stats = G > 0: the output feeds a GroupNorm(G) - where the planned tile can, the copy-out also leaves the norm's partial
+    statistics (include/pbe_hip.h, group_stats_out) and the returned tensor carries them (`_pbe_gstats`); ops.groupnorm then runs its
+    normalisation pass only."""
     _h(x, "conv3x3 x"); _h(wp, "conv3x3 w")
     if x.dim() != 4 or not x.is_contiguous():
         raise _l.PbeError("conv3x3: x must be a contiguous [B,H,W,C] tensor")
@@ -361,12 +364,19 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
         _f(bias, "conv3x3 bias")
     d = _l.Conv3x3Desc(_p(x), _p(x2), _p(wp), _p(y), _p(bias), _p(rowvec), _p(resid), B, H, W, C1, C2, Cout, stride, pad,
                        1 if upsample else 0, ldv, act, _splitk_ws(x.device).data_ptr(), SPLITK_WS_BYTES,
-                       _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"), conv_kblock(C1, C2))
+                       _tile_cfg(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"), conv_kblock(C1, C2), None, 0, None)
+    gs_buf = gs_blocks = None
+    if group_stats > 0 and USE_CONV_GROUP_STATS and Cout % group_stats == 0 and Ho * Wo >= 64:
+        gs_buf = torch.empty((B, (Ho * Wo) // 64, group_stats, 2), dtype=torch.float32, device=x.device)       # room for the smallest row block (64)
+        gs_blocks = C.c_int32(0)
+        d.group_stats_out, d.group_stats_groups, d.group_stats_blocks = gs_buf.data_ptr(), group_stats, C.cast(C.pointer(gs_blocks), C.c_void_p)
     if _PIN_SCALE != 1:
         d.tile_cfg = _pinned_cfg(d, lambda sc: f"c:{B * sc}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}", True)
     _launch_note(d, f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}", True)
     with _timed(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"):
         _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
+    if gs_blocks is not None and gs_blocks.value > 0:
+        y._pbe_gstats = GroupStats(gs_buf, B, int(gs_blocks.value), group_stats)
     return y
 
 
@@ -380,6 +390,21 @@ def conv3x3_small(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor
     _l.check(_l.load().pbe_im2col3x3_f16(_p(x), _p(cols), B, H, W, Cp, stride, pad, _stream()), "pbe_im2col3x3_f16")
     y = gemm(cols, wp, bias, act=act, resid=None if resid is None else resid.reshape(B * Ho * Wo, -1))
     return y.view(B, Ho, Wo, wp.shape[0])
+
+
+USE_CONV_GROUP_STATS = True      # conv3x3(group_stats=G): let the conv's copy-out produce the following GroupNorm's statistics (tools flip it for A/B)
+
+
+class GroupStats:
+    """Partial (sum, sumsq) per (sample, row block, group) of a conv output, written by the conv's copy-out: the first B * blocks * groups * 2
+    floats of `buf`, laid out [B][blocks][groups][2] (pbe_groupnorm_f16's partial layout)."""
+    __slots__ = ("buf", "blocks", "groups", "batch")
+
+    def __init__(self, buf, batch, blocks, groups):
+        self.buf, self.batch, self.blocks, self.groups = buf, batch, blocks, groups
+
+    def view(self):
+        return self.buf.view(-1)[: self.batch * self.blocks * self.groups * 2].view(self.batch, self.blocks, self.groups, 2)
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, *, x2: Optional[torch.Tensor] = None,
@@ -399,6 +424,14 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     if gamma.numel() != C1 + C2 or beta.numel() != C1 + C2:
         raise _l.PbeError("groupnorm: affine length mismatch")
     lib = _l.load()
+    st = getattr(x, "_pbe_gstats", None)
+    if st is not None and x2 is None and st.groups == groups and st.batch == B:
+        # the producing conv left this tensor's statistics: normalisation pass only (one read, one write)
+        y = torch.empty_like(x)
+        with _timed(f"n:{B}:{HW}:{C1}:0"):
+            _l.check(lib.pbe_groupnorm_apply_f16(_p(x), _p(st.buf), st.blocks, _p(gamma), _p(beta), _p(y), B, HW, C1, groups, float(eps), 1 if silu else 0,
+                                                 _stream()), "pbe_groupnorm_apply_f16")
+        return y
     need = lib.pbe_groupnorm_workspace_bytes(B, HW)
     key = (x.device.index, "gn")
     ws = _ws.get(key)

@@ -32,7 +32,7 @@ def test_documented_stub_matches_the_abi():
     assert C.sizeof(G) == C.sizeof(L.GemmDesc) == L.load().pbe_sizeof_gemm_desc()
     assert [(n, C.sizeof(t)) for n, t in G._fields_] == [(n, C.sizeof(t)) for n, t in L.GemmDesc._fields_]
     assert [getattr(G, n).offset for n, _ in G._fields_] == [getattr(L.GemmDesc, n).offset for n, _ in L.GemmDesc._fields_]
-    assert L.load().pbe_abi_version() == L.ABI_VERSION == 7
+    assert L.load().pbe_abi_version() == L.ABI_VERSION == 8
     assert C.sizeof(L.Conv3x3Desc) == L.load().pbe_sizeof_conv3x3_desc() and C.sizeof(L.AttnDesc) == L.load().pbe_sizeof_attn_desc()
 
 

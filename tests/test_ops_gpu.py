@@ -419,6 +419,48 @@ def test_gemm_layernorm_fold(dev, M, N, K, act):
     assert e_new <= 1.5 * e_old + 1e-4, (e_new, e_old)                      # no worse than the separate-LayerNorm path it replaces
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,resid,cfg", [(8, 64, 320, 320, False, -1), (8, 64, 320, 320, True, -1), (8, 32, 640, 640, True, -1), (2, 64, 320, 320, True, 9),
+                                                     (2, 32, 640, 640, False, 11), (4, 32, 320, 640, False, 3), (3, 64, 640, 320, True, 13), (8, 16, 1280, 1280, False, -1)])
+def test_conv_group_statistics_feed_groupnorm(dev, B, H, Cin, Cout, resid, cfg):
+    """conv3x3(group_stats=32): the conv's copy-out leaves the following GroupNorm's partial statistics (halo, gather and 4-wave tiles, with and
+    without the fused residual) and ops.groupnorm then runs its normalisation pass only - against the two-pass GroupNorm of the same
+    tensor (summation order differs: close, not identical) and torch fp32.  Where the tile cannot (split-K at 16x16) the tensor carries none."""
+    from pbe_amd import ops
+    g = _g(B + H + Cin + Cout)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 0.7).half().to(dev)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    bias, emb = torch.randn(Cout, generator=g).to(dev) * 0.1, (torch.randn(B, Cout, generator=g) * 0.3).half().to(dev)
+    r = (torch.randn(B, H, H, Cout, generator=g) * 0.8 + 0.3).half().to(dev) if resid else None
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).to(dev), (0.1 * torch.randn(Cout, generator=g)).to(dev)
+    wp = ops.pack_conv3x3(w).to(dev)
+    kw = dict(resid=r) if resid else dict(rowvec=emb)
+    try:
+        ops._FORCE_CFG = None if cfg < 0 else cfg
+        y = ops.conv3x3(x, wp, bias, group_stats=32, **kw)
+        plain = ops.conv3x3(x, wp, bias, **kw)
+    finally:
+        ops._FORCE_CFG = None
+    assert torch.equal(y, plain)                                           # the stored values do not depend on the statistics path
+    st = getattr(y, "_pbe_gstats", None)
+    if H == 16 or (cfg >= 0 and st is None):
+        assert st is None                                                  # split-K (the reduce kernel stores the output), or a forced tile whose columns
+        got = ops.groupnorm(y, gamma, beta, 1e-5, True)                    # are not whole groups (128 columns): the two-pass norm runs as before
+        assert torch.equal(got, ops.groupnorm(plain, gamma, beta, 1e-5, True))
+        return
+    assert st is not None and st.groups == 32 and st.blocks > 0 and (H * H) % st.blocks == 0
+    tot = st.view().double().sum(1).cpu()                                  # [B, 32, 2]
+    yg = y.double().cpu().view(B, H * H, 32, Cout // 32)
+    want = torch.stack([yg.sum((1, 3)), (yg ** 2).sum((1, 3))], -1)
+    assert torch.allclose(tot, want, rtol=2e-6, atol=1e-3), (tot - want).abs().max()
+    got = ops.groupnorm(y, gamma, beta, 1e-5, True)
+    two = ops.groupnorm(plain, gamma, beta, 1e-5, True)
+    assert (got.float() - two.float()).abs().max().item() <= 4e-3         # two summation orders of the same statistics
+    ref = F.silu(F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 3, 1)
+    _close(got, ref, rtol=3e-3, atol=3e-3, what="GroupNorm from the conv's statistics")
+    y2 = ops.conv3x3(x, wp, bias, group_stats=32, **kw)
+    assert torch.equal(y2._pbe_gstats.view(), st.view())                   # deterministic
+
+
 @pytest.mark.parametrize("M", [32768, 16384, 2048, 1280])
 def test_gemm_a_stationary_matches_streaming_tile(dev, M):
     """Tile configs 19 / 20 (igemm_astat.hip: the K = 320 LayerNorm-folded GEGLU projection with the A block in registers and only the
