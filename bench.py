@@ -401,7 +401,7 @@ def main():
             classes[k] = row
         dom = max((k for k in classes if k in MFMA), key=lambda k: classes[k]["ms"])           # the class with the most GPU time
         d = classes[dom]
-        names = {"conv3x3_igemm": "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)", "gemm": "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)",
+        names = {"conv3x3_igemm": "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)", "gemm": "igemm_kernel<*,*,*,*,0,*> + astat_regs_kernel<*,*> (Linear / 1x1 conv GEMM)",
                  "attention": "attn_kernel<*,*,*> (fused self-attention)"}
         line["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": d["frac"], "traffic": d["traffic"], "traffic_unit": "B per launch (L2-fabric side)", "traffic_source": traffic_src,

@@ -57,7 +57,7 @@ def main(fdir, wdir, outp):
     # every class of bench.py's roofline.classes: the two igemm classes by MODE, the others by kernel name (all of them move 16 B per lane:
     # LDS-DMA pieces, h16x8 / f32x4 loads and stores - the access shape the guide's FETCH_SIZE x 2 correction is calibrated for)
     sel = (("conv3x3_igemm", lambda k: mode_of(k) in ("1", "2"), "igemm_kernel<*,*,*,*,1|2,*> (3x3 conv: gather and halo-resident implicit GEMM)"),
-           ("gemm", lambda k: mode_of(k) == "0", "igemm_kernel<*,*,*,*,0,*> (Linear / 1x1 conv GEMM)"),
+           ("gemm", lambda k: mode_of(k) == "0" or "astat_regs_kernel" in k, "igemm_kernel<*,*,*,*,0,*> + astat_regs_kernel<*,*> (Linear / 1x1 conv GEMM)"),
            ("attention", lambda k: "attn_kernel" in k, "attn_kernel<*> (fused self-attention)"),
            ("groupnorm", lambda k: any(n in k for n in ("gn_stats_kernel", "gn_apply_kernel", "gn_small_kernel")), "gn_stats + gn_apply, gn_small"),   # (non-template kernels arrive mangled)
            ("layernorm", lambda k: any(n in k for n in ("layernorm_kernel", "layernorm_f8_kernel", "row_stats_kernel")), "layernorm / row statistics kernels"),
