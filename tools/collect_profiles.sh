@@ -15,7 +15,7 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- $BENCH > /dev
 echo "[collect] WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- $BENCH > /dev/null 2> $O/pmc_w.stderr.txt || exit 1
 echo "[collect] MFMA / VALU utilisation"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-include-regex "igemm_kernel|attn_kernel" \
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-include-regex "igemm_kernel|attn_kernel|astat_regs_kernel" \
     -d $O/pmc_m -o p --output-format csv -- $BENCH > /dev/null 2> $O/pmc_m.stderr.txt || exit 1
 cd $R
 python3 tools/pmc_bench_traffic.py $O/pmc_f $O/pmc_w $O/igemm_traffic.json > $O/traffic_summary.txt || exit 1

@@ -2,7 +2,7 @@
 """MFMA and VALU utilisation of the matrix-core kernels over one bench pass, from ONE rocprofv3 PMC pass:
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES \\
-        --kernel-include-regex "igemm_kernel|attn_kernel" -d gpurun_out/pmc_mfma/p -o p --output-format csv -- \\
+        --kernel-include-regex "igemm_kernel|attn_kernel|astat_regs_kernel" -d gpurun_out/pmc_mfma/p -o p --output-format csv -- \\
         python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile
     python tools/pmc_mfma_util.py gpurun_out/pmc_mfma/p profiles/r01_mfma_utilisation.json
 
@@ -29,6 +29,8 @@ def main(d, outp):
         if name.startswith("igemm_kernel<"):
             args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
             klass = "conv3x3_igemm" if args[4] in ("1", "2") else "gemm"          # MODE 1 gather / 2 halo-resident conv, 0 dense
+        elif name.startswith("astat_regs_kernel<"):
+            klass = "gemm"                                                        # the A-stationary K = 320 tiles (igemm_astat.hip)
         elif name.startswith("attn_kernel<"):
             klass = "attention"
         else:
