@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
 #pragma unroll
         for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const h16x8*>(sw + w_rd + rsw + i * 16 * 128);
         __builtin_amdgcn_sched_barrier(0);
-        // the DMA pieces of k-tile q + 2 go out behind the fragment reads (in the shadow of the first k-step's MFMAs they cost the wave the
-        // same ~110 cycles each - tools/astat_stamps.py - and delay the second k-step's reads)
+        // the DMA pieces of k-tile q + 2 go out behind the fragment reads (in the shadow of the first k-step's MFMAs, as a burst or one piece
+        // per four MFMAs, they cost the wave the same ~110 cycles each - tools/astat_stamps.py - and delay the second k-step's reads)
         if (q + 2 < Q) issue_w();
         float vb = 0.f, vc = 0.f;
         if (kt == 2 && tid < BN) {                        // this tile's epilogue vectors -> LDS (read after the barriers of k-tiles 3 and 4)
