@@ -52,16 +52,27 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
     // ---- prologue, in vmcnt order: [W0] [LayerNorm statistics] [A fragments, 20 loads] [W1]: the first k-tile needs W0 and the k-tile 0
     //      fragments only, the other 16 fragment loads and W1 stay in flight behind it ----
     const int lrow = lane >> 3, gch = (lane & 7) ^ lrow;
+    // every workgroup of the chip streams the SAME weight tiles: each starts its run at another tile (rot) so that at one moment the
+    // workgroups read different lines of the L2 (pbe_tune-free A/B: PBE_ASTAT_NOROT)
+#ifdef PBE_ASTAT_NOROT
+    const int rot = 0;
+#else
+    const int rot = (mb + (mb >> 3)) % run;
+#endif
     const h16* w_src[PW];
 #pragma unroll
-    for (int i = 0; i < PW; ++i) w_src[i] = p.W + ((long)nt0 * BN + (wm + 4 * i) * 8 + lrow) * p.ldw + gch * 8;
-    const long w_next_tile = (long)BN * p.ldw - (AKT - 1) * 64;
-    int wq_kt = 0, wq_slot = 0;
+    for (int i = 0; i < PW; ++i) w_src[i] = p.W + ((long)(nt0 + rot) * BN + (wm + 4 * i) * 8 + lrow) * p.ldw + gch * 8;
+    const long w_next_tile = (long)BN * p.ldw - (AKT - 1) * 64, w_wrap = -(long)run * BN * p.ldw;
+    int wq_kt = 0, wq_slot = 0, wq_tile = rot;
     auto issue_w = [&]() {
         unsigned char* dst = smem + wq_slot * SLOT;
 #pragma unroll
         for (int i = 0; i < PW; ++i) PBE_GLDS16(w_src[i], dst + (wm + 4 * i) * 1024);
-        const long adv = wq_kt == AKT - 1 ? w_next_tile : 64;
+        long adv = 64;
+        if (wq_kt == AKT - 1) {
+            adv = w_next_tile;
+            if (++wq_tile == run) { wq_tile = 0; adv += w_wrap; }
+        }
 #pragma unroll
         for (int i = 0; i < PW; ++i) w_src[i] += adv;
         wq_kt = wq_kt == AKT - 1 ? 0 : wq_kt + 1;
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) astat_regs_kernel(const IGemmP p, int 
     };
     using std::integral_constant;
     for (int t = 0; t < run; ++t) {
-        const int n0 = (nt0 + t) * BN, sbuf = t & 1;
+        const int n0 = (nt0 + (t + rot >= run ? t + rot - run : t + rot)) * BN, sbuf = t & 1;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
