@@ -376,7 +376,7 @@ def conv3x3(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], *, 
     with _timed(f"c:{B}:{H}:{W}:{C1}:{C2}:{Cout}:{stride}:{pad}:{int(bool(upsample))}"):
         _l.check(_l.load().pbe_conv3x3_f16(C.byref(d), _stream()), "pbe_conv3x3_f16")
     if gs_blocks is not None and gs_blocks.value > 0:
-        y._pbe_gstats = GroupStats(gs_buf, B, int(gs_blocks.value), group_stats)
+        y._pbe_gstats = GroupStats(gs_buf, B, int(gs_blocks.value), group_stats, y._version)
     return y
 
 
@@ -398,10 +398,10 @@ USE_CONV_GROUP_STATS = True      # conv3x3(group_stats=G): let the conv's copy-o
 class GroupStats:
     """Partial (sum, sumsq) per (sample, row block, group) of a conv output, written by the conv's copy-out: the first B * blocks * groups * 2
     floats of `buf`, laid out [B][blocks][groups][2] (pbe_groupnorm_f16's partial layout)."""
-    __slots__ = ("buf", "blocks", "groups", "batch")
+    __slots__ = ("buf", "blocks", "groups", "batch", "version")
 
-    def __init__(self, buf, batch, blocks, groups):
-        self.buf, self.batch, self.blocks, self.groups = buf, batch, blocks, groups
+    def __init__(self, buf, batch, blocks, groups, version):
+        self.buf, self.batch, self.blocks, self.groups, self.version = buf, batch, blocks, groups, version      # version: the tensor's _version when written
 
     def view(self):
         return self.buf.view(-1)[: self.batch * self.blocks * self.groups * 2].view(self.batch, self.blocks, self.groups, 2)
@@ -425,7 +425,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         raise _l.PbeError("groupnorm: affine length mismatch")
     lib = _l.load()
     st = getattr(x, "_pbe_gstats", None)
-    if st is not None and x2 is None and st.groups == groups and st.batch == B:
+    if st is not None and x2 is None and st.groups == groups and st.batch == B and st.version == x._version:      # (an in-place edit since the conv voids them)
         # the producing conv left this tensor's statistics: normalisation pass only (one read, one write)
         y = torch.empty_like(x)
         with _timed(f"n:{B}:{HW}:{C1}:0"):
