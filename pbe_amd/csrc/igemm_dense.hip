@@ -22,6 +22,7 @@ void pbe_dispatch_dense(IGemmP p, int batch, hipStream_t s, size_t ws_bytes, int
         case 16: launch_cfg<128, 64, 2, 2, 4, MODE>(p, batch, s); break;
         case 17: launch_cfg<64, 64, 2, 2, 4, MODE>(p, batch, s); break;
         case 18: launch_cfg<128, 160, 2, 2, 4, MODE>(p, batch, s); break;
+        case 21: launch_cfg<256, 160, 4, 2, 3, MODE>(p, batch, s); break;
         default: launch_cfg<64, 64, 2, 2, 2, MODE>(p, batch, s); break;
     }
 }

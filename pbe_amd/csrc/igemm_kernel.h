@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
     constexpr int CLD = BN + 8;
     // MODE 2 LDS: [halo image 0][halo image 1][weight ring S x BN rows]
     constexpr int RING = MODE == 2 ? 2 * HPA * 128 + S * W_BYTES : S * STAGE;
-    static_assert(S >= 2 && S <= 4 && PA % NW == 0 && (PW % NW == 0 || MODE == 2) && BM % 16 == 0 && BN % 16 == 0, "pieces must divide over the waves");
+    static_assert(S >= 2 && S <= 4 && PA % NW == 0 && BM % 16 == 0 && BN % 16 == 0, "A pieces must divide over the waves (weight pieces may be padded)");
     static_assert(MODE != 2 || (HPA % 8 == 0 && HPA >= BM), "halo image must hold the tile");
     static_assert(EX == 0 || (MODE == 0 && !F8), "extended epilogue: dense fp16 tiles only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -361,10 +361,10 @@ __global__ void __launch_bounds__(NWM* NWN * 64, ((EX & 4) != 0 && NWM * NWN == 
         }
         if (!slow) {
 #pragma unroll
-            for (int i = 0; i < LW; ++i) PBE_GLDS16(w_row[i] + k, sw + (wave + NW * i) * 1024);
+            for (int i = 0; i < LW; ++i) PBE_GLDS16(w_row[i] + k, sw + min(wave + NW * i, PW - 1) * 1024);      // (a padding piece repeats the last real one)
         } else {
 #pragma unroll
-            for (int i = 0; i < LW; ++i) PBE_GLDS16(kl < p.K ? w_row[i] + k : zsrc, sw + (wave + NW * i) * 1024);
+            for (int i = 0; i < LW; ++i) PBE_GLDS16(kl < p.K ? w_row[i] + k : zsrc, sw + min(wave + NW * i, PW - 1) * 1024);
         }
     };
 
@@ -1267,7 +1267,9 @@ static const TileCfg kCfg[] = {
     // A-stationary persistent tiles (igemm_astat.hip): K = 320 GEGLU projection with the LayerNorm fold, A block in registers, 4 waves,
     // two workgroups per CU; never picked by the heuristic (eff 0), only through desc.tile_cfg / the tuned table where pbe_astat_ok() holds
     {128, 128, 4, 1, 2, 0.0},            // 19: weight ring 48 KiB
-    {128, 160, 4, 1, 2, 0.0}};           // 20: weight ring 60 KiB (256 registers, 14 spilled)
+    {128, 160, 4, 1, 2, 0.0},            // 20: weight ring 60 KiB (256 registers, 14 spilled)
+    // dense 8-wave tile with 160 columns: 6.5 LDS-DMA pieces per wave and k-tile against 40 MFMAs (the 4-wave 128x160 tile: 9)
+    {256, 160, 4, 2, 1, 0.0}};           // 21: S = 3, 156 KiB (MODE 0 only; through the tuned table)
 static const int kNCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 #ifdef PBE_STAMPS
@@ -1301,7 +1303,7 @@ static int splits_for(const IGemmP& p, const TileCfg& c, int batch, size_t ws_by
 // FLOP.  Both efficiency rows are fitted to the 472 measured shapes of profiles/r01_autotune_report.txt (the
 // heuristic then costs 4 % over the best tile per shape, 12 % before the fit).  pbe_amd/tuned_mi355x.json overrides
 // this per shape (desc.tile_cfg), so these rows only decide shapes outside the table.
-static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1, 0.5, 0.4, 0.38, 0.52, 0.0, 0.0};
+static const double kEffShallow[] = {0.82, 0.72, 0.66, 1.00, 0.84, 0.85, 0.80, 0.80, 0.95, 0.97, 1.4, 1.2, 1.25, 1.3, 1.1, 0.5, 0.4, 0.38, 0.52, 0.0, 0.0, 0.0};
 
 // Can this conv run as a halo-resident tile of bm pixels with a halo image of hpa rows?  Returns the image rows per tile (0: no).
 static int halo_rows(const IGemmP& p, int mode, int bm, int hpa) {
@@ -1335,7 +1337,7 @@ static Plan plan_igemm(const IGemmP& p, int batch, size_t ws_bytes, int want_cfg
     for (int c = 0; c < kNCfg; ++c) {
         if (forced >= 0 && c != forced) continue;
         TileCfg t = kCfg[c];
-        if (c >= 19 && (forced != c || mode != 0 || !pbe_astat_ok(p, batch, c))) continue;
+        if (c >= 19 && (forced != c || mode != 0 || (c < 21 && !pbe_astat_ok(p, batch, c)))) continue;
         if (ex_needed(p) && (!(kExCfgs >> c & 1) || (p.vt && p.vt_col0 % t.bn))) continue;   // extended epilogue: its tiles only, V^T columns start on a tile
         if (t.hpa && !halo_rows(p, mode, t.bm, t.hpa)) continue;              // a forced halo tile that does not apply falls back below
         if (t.hpa && p.N % 8) continue;

@@ -917,7 +917,7 @@ def test_gemm_ragged_k_and_straddling_concat(dev, K1, K2):
     bias = torch.randn(N, generator=g)
     ref = (torch.cat([a1, a2], 1).float() @ w.float().t() + bias).half().float()
     try:
-        for cfg in (-1, 3, 6, 9, 1, 17):
+        for cfg in (-1, 3, 6, 9, 1, 17, 21):               # 21: 8 waves x 160 columns - 20 weight pieces over 8 waves, the padding pieces repeat the last one
             ops.tune(1, cfg)
             _close(ops.gemm(a1.to(dev), w.to(dev), bias.to(dev), a2=a2.to(dev)), ref, what=f"gemm K1={K1} K2={K2} cfg {cfg}")
             ops.tune(1, -1)
@@ -925,6 +925,29 @@ def test_gemm_ragged_k_and_straddling_concat(dev, K1, K2):
         _close(ops.gemm(aw.to(dev), w.to(dev), bias.to(dev)), ref, what=f"gemm K={K1 + K2} single source")
     finally:
         ops.tune(1, -1)
+
+
+def test_dense_256x160_tile_matches_128x160(dev):
+    """Tile 21 (256x160, 8 waves, ring of 3: the ff-out / out-projection of the 64x64 level through the tuned table) against the 4-wave
+    128x160 tile: same accumulation order, bit-identical with and without the fused residual, on the tile grid and off it."""
+    from pbe_amd import ops
+    g = _g(21)
+    for (M, N, K) in ((4096, 320, 1280), (1000, 300, 320), (512, 640, 704)):
+        a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        r = torch.randn(M, N, generator=g).half().to(dev)
+        outs = {}
+        try:
+            for cfg in (9, 21):
+                ops._FORCE_CFG = cfg
+                ops._PLANS = []
+                outs[cfg] = (ops.gemm(a, w, b), ops.gemm(a, w, b, resid=r if N % 8 == 0 else None))
+                assert ops._PLANS[0][1] == cfg, ops._PLANS
+        finally:
+            ops._FORCE_CFG, ops._PLANS = None, None
+        assert torch.equal(outs[9][0], outs[21][0]) and torch.equal(outs[9][1], outs[21][1])
+        _close(outs[21][0], a.float().cpu() @ w.float().cpu().t() + b.cpu(), rtol=3e-3, atol=3e-3, what=f"dense 256x160 {M}x{N}x{K}")
 
 
 def test_xcd_tile_order_is_bit_neutral(dev):
