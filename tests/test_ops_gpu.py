@@ -461,6 +461,25 @@ def test_conv_group_statistics_feed_groupnorm(dev, B, H, Cin, Cout, resid, cfg):
     assert torch.equal(y2._pbe_gstats.view(), st.view())                   # deterministic
 
 
+def test_conv_group_statistics_are_dropped_after_an_in_place_edit(dev):
+    """The statistics a conv leaves with its output describe the values it stored: an in-place edit of the tensor afterwards (its
+    _version moves) must send ops.groupnorm back to the two-pass kernels."""
+    from pbe_amd import ops
+    g = _g(5)
+    x = (torch.randn(2, 64, 64, 320, generator=g) * 0.7).half().to(dev)
+    wp = ops.pack_conv3x3(torch.randn(320, 320, 3, 3, generator=g) / 54.0).to(dev)
+    gamma, beta = torch.ones(320, device=dev), torch.zeros(320, device=dev)
+    y = ops.conv3x3(x, wp, None, group_stats=32)
+    assert getattr(y, "_pbe_gstats", None) is not None
+    y.mul_(2.0)
+    got = ops.groupnorm(y, gamma, beta, 1e-5, False)
+    ref = F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, None, None, 1e-5).permute(0, 2, 3, 1)
+    _close(got, ref, rtol=3e-3, atol=3e-3, what="GroupNorm after an in-place edit")
+    z = ops.conv3x3(x, wp, None, group_stats=32)
+    _close(ops.groupnorm(z, gamma, beta, 1e-5, False), F.group_norm(z.float().cpu().permute(0, 3, 1, 2), 32, None, None, 1e-5).permute(0, 2, 3, 1),
+           rtol=3e-3, atol=3e-3, what="GroupNorm from the conv's statistics, no affine")
+
+
 @pytest.mark.parametrize("M", [32768, 16384, 2048, 1280])
 def test_gemm_a_stationary_matches_streaming_tile(dev, M):
     """Tile configs 19 / 20 (igemm_astat.hip: the K = 320 LayerNorm-folded GEGLU projection with the A block in registers and only the
