@@ -9,7 +9,7 @@ void pbe_dispatch_ex(IGemmP p, int batch, hipStream_t s, int want_cfg) {
 #ifdef PBE_STAMPS
     p.stamps = g_pbe_stamps;
 #endif
-    if (pl.cfg >= 19) { pbe_launch_astat(pl.cfg, p, s); return; }
+    if (pl.cfg == 19 || pl.cfg == 20) { pbe_launch_astat(pl.cfg, p, s); return; }      // (plan_igemm admits them only where pbe_astat_ok holds)
     // (the ln / qkv instantiations fold unconditionally: they are only ever launched with ln_stat)
     const bool ln = p.ln_stat != nullptr, st = p.rstat != nullptr, vt = p.vt != nullptr || p.alpha_cols > 0;
     if (ln && !st && !vt) pbe_launch_ex_ln(pl.cfg, p, batch, s);
