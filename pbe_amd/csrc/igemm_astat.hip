@@ -3,7 +3,7 @@
 //
 // Why: with K = 320 an output tile of the streaming kernel (igemm_kernel.h) lives for 5 k-tiles; its ring (one k-tile in flight per
 // workgroup) drains at every tile, the first tile waits a full memory round trip, and every k-tile costs each wave 9 LDS-DMA pieces
-// (A and W) at ~110 cycles of issue each against 20 MFMAs (tools/astat_stamps.py).  Here a workgroup keeps its 128 rows of A for a RUN
+// (A and W) at ~110 cycles of issue each against 40 MFMAs (tools/astat_stamps.py).  Here a workgroup keeps its 128 rows of A for a RUN
 // of column tiles and streams only the weights (L2-resident: 1.6 MB for N = 2 560): 4 pieces per wave and k-tile against 32 MFMAs, a
 // ring that never drains (the next tile's first two weight k-tiles land during the epilogue), no per-tile prologue.
 //
